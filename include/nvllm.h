@@ -1,0 +1,139 @@
+/*
+ * nvllm.h -- entry points of libnvllm_hip.so that have no one-to-one counterpart
+ * in the reference's headers: device selection, result hand-off modes, kernel
+ * timing, and an N-sequence driver that restates the scheduler loop which the
+ * reference hard-codes for two sequences inside main() (src/main.c:151-166,
+ * 259-419).  Plain C ABI: pointers, ints, no C++ or torch types.
+ */
+#ifndef NVLLM_H
+#define NVLLM_H
+
+#include "structs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Select the GPU every later call of this process uses (one process per GPU).
+ * Must be called before init_ops()/device_malloc(); default is device 0. */
+int nvllm_set_device(int ordinal);
+
+/* hipStream_t on which the library enqueues every kernel and copy. */
+void* nvllm_stream(void);
+
+/* What transformer_batch copies back to the host for each output row.
+ *   NVLLM_LOGITS_HOST   (default, the reference's contract, main.c:377): the
+ *                       full fp32 row lands in RunState.logits.
+ *   NVLLM_LOGITS_ARGMAX only the index of the row maximum is copied back
+ *                       (4 bytes instead of vocab_size*4); RunState.logits is
+ *                       left untouched and sample() with temperature 0 answers
+ *                       from those indices. */
+enum { NVLLM_LOGITS_HOST = 0, NVLLM_LOGITS_ARGMAX = 1 };
+void nvllm_set_logits_mode(int mode);
+int  nvllm_get_logits_mode(void);
+
+/* Arg-max indices of the most recent transformer_batch call (host array with
+ * num_outputs entries, valid until the next call). */
+const int* nvllm_last_argmax(int* num_outputs);
+
+/* Element type of the KV pool that init_kv_cache_manager allocates next:
+ * 4 = fp32 (reference layout, bit-exact copies), 2 = fp16 (half the bytes,
+ * values rounded to nearest-even on write). */
+void nvllm_set_kv_elem_bytes(int bytes);
+int  nvllm_get_kv_elem_bytes(void);
+
+/* Replay identical consecutive decode-shaped forward passes from a captured
+ * hipGraph instead of launching kernel by kernel (0 = off, 1 = on). */
+void nvllm_set_graph_mode(int on);
+
+/* ---------------------------------------------------------- kernel timing */
+/* With timing on, every kernel launch is bracketed by a pair of HIP events on
+ * the library stream.  Classes are small integers; nvllm_prof_name() names them. */
+void nvllm_prof_enable(int on);
+void nvllm_prof_reset(void);
+int  nvllm_prof_num_classes(void);
+const char* nvllm_prof_name(int cls);
+/* Sums since the last reset: launches, total milliseconds, algorithmic bytes
+ * (what the kernel must read+write at least once) and flops.  Resolves pending
+ * events (synchronises the stream). */
+void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* bytes, double* flops);
+
+/* ------------------------------------------------------ N-sequence driver */
+/* The reference's scheduler with the sequence count as a parameter: arrival
+ * gating, is_prefill = pos < n_prompt-1, chunked prefill, batch-capacity check,
+ * one block allocated whenever a position is a multiple of block_size, one
+ * sample() per scheduled sequence per step -- including mid-prefill chunks,
+ * whose sample overwrites current_token exactly as main.c:353-355,402 do. */
+typedef struct NvllmEngine NvllmEngine;
+
+typedef struct {
+    int chunk_size;      /* --chunk-size; <= 0 means unlimited (main.c:80)          */
+    int block_size;      /* 0 -> 16 (main.c:188)                                    */
+    int num_blocks;      /* 0 -> n_seqs * ceil(max_seq_len/block_size) (main.c:189) */
+    int max_seq_len;     /* 0 -> header value; raised to >= 1024 if raise_to_1024   */
+    int raise_to_1024;   /* main.c:140-143                                          */
+    int recycle_blocks;  /* 1: free_block() every block of a sequence when it
+                               finishes (the reference never does, memory.c:64-70)  */
+    int max_steps;       /* 0 -> 500 (main.c:418); the loop stops when step > this  */
+    float temperature;   /* 0 => greedy                                             */
+    float topp;
+    unsigned long long seed;
+} NvllmEngineOptions;
+
+typedef struct {
+    long long steps;            /* scheduler iterations that ran a forward pass */
+    long long tokens_forwarded; /* sum of batch sizes                           */
+    long long prefill_tokens;   /* tokens forwarded by prefill chunks           */
+    long long decode_tokens;    /* tokens forwarded by decode rows              */
+    long long outputs;          /* sample() calls                               */
+    double forward_seconds;     /* wall time inside transformer_batch           */
+    double sample_seconds;      /* wall time inside sample()                    */
+    double prefill_step_seconds;/* forward time of steps containing any prefill */
+    double decode_step_seconds; /* forward time of pure-decode steps            */
+    long long decode_step_tokens;/* tokens forwarded by pure-decode steps       */
+    long long prefill_step_tokens;
+} NvllmEngineStats;
+
+NvllmEngine* nvllm_engine_create(const char* model_path, int n_seqs, const NvllmEngineOptions* opt);
+void nvllm_engine_destroy(NvllmEngine* e);
+
+/* Define sequence `seq`: prompt token ids (copied), number of tokens to generate
+ * and the scheduler step at which it arrives.  Returns 0, or -1 on bad input. */
+int nvllm_engine_set_request(NvllmEngine* e, int seq, const int* prompt, int n_prompt,
+                             int n_new, int arrival_step);
+
+/* One iteration of the loop at main.c:259-419.  Returns 1 while work remains,
+ * 0 once every sequence has finished (or the step cap was hit). */
+int nvllm_engine_step(NvllmEngine* e);
+/* Up to `n` iterations; returns how many ran before the loop ended. */
+int nvllm_engine_run(NvllmEngine* e, int n);
+
+int  nvllm_engine_global_step(const NvllmEngine* e);
+void nvllm_engine_get_stats(const NvllmEngine* e, NvllmEngineStats* out);
+void nvllm_engine_reset_stats(NvllmEngine* e);
+const Config* nvllm_engine_config(const NvllmEngine* e);
+
+/* Per-sequence state: returns pos; copies min(cap, filled) history entries. */
+int nvllm_engine_seq_state(const NvllmEngine* e, int seq, int* status, int* current_token,
+                           int* n_prompt, int* seq_len);
+int nvllm_engine_history(const NvllmEngine* e, int seq, int* out, int cap);
+int nvllm_engine_block_table(const NvllmEngine* e, int seq, int* out, int cap);
+
+/* The ragged batch of the most recent forward pass. */
+int nvllm_engine_last_batch(const NvllmEngine* e, int* tokens, int* pos, int* seq_ids, int cap,
+                            int* output_indices, int* sampled, int out_cap, int* num_outputs);
+/* Host logits of the most recent forward pass ([num_outputs, vocab]); valid in
+ * NVLLM_LOGITS_HOST mode only. */
+const float* nvllm_engine_logits(const NvllmEngine* e);
+
+/* Allocation trace: every alloc_block() the scheduler made, in order, as
+ * (seq, logical_block, physical_block) triples.  Returns the number of triples. */
+int nvllm_engine_alloc_trace(const NvllmEngine* e, int* out, int cap_triples);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NVLLM_H */

@@ -1,0 +1,369 @@
+/*
+ * engine.c -- N-sequence continuous-batching driver (host C).
+ *
+ * The reference's scheduler lives inside main() and is fixed at two sequences
+ * with built-in prompts (src/main.c:151-166, 259-419).  This file restates that
+ * loop with the sequence count, prompts, arrival steps and generation lengths as
+ * inputs, so that every batch it builds, every block it allocates and every
+ * token it feeds back is what main() would produce for the same requests.  It
+ * talks to the forward pass only through include/ops.h, include/model.h and
+ * include/sampler.h, so one object file serves the HIP library, the CPU oracle
+ * and the reference build alike.
+ */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "model.h"
+#include "nvllm.h"
+#include "ops.h"
+#include "sampler.h"
+#include "structs.h"
+
+/* The reference's driver defines these three (src/main.c:51-55) and model.c reads
+ * two of them through `extern`.  Weak, so that an executable that brings its own
+ * main.c definitions wins. */
+__attribute__((weak)) int g_visualize_paged = 0;
+__attribute__((weak)) int g_paged_mode = 1;
+__attribute__((weak)) KVCacheManager g_kv_manager;
+
+/* Optional: a backend that can release what load_model allocated exports this
+ * (the reference has no free_model and simply leaks at exit). */
+extern void nvllm_free_model(Weights* w) __attribute__((weak));
+
+struct NvllmEngine {
+    NvllmEngineOptions opt;
+    Config config;
+    Weights weights;
+    RunState state;
+    Sampler sampler;
+    int n_seqs;
+    Sequence* seqs;
+    int* history_cap;
+    int capacity;          /* MAX_BATCH_CAPACITY = max_seq_len tokens (main.c:148) */
+    int max_blocks_per_seq;
+    int global_step;
+    int finished;
+    /* batch buffers (main.c:249-256) */
+    int* batch_tokens;
+    int* batch_pos;
+    int* batch_seq_ids;
+    int* batch_output_indices;
+    int* batch_sampled;
+    BlockTable** batch_block_tables;
+    int last_batch_count;
+    int last_output_count;
+    /* allocation trace */
+    int* trace;
+    int trace_len, trace_cap;
+    NvllmEngineStats stats;
+};
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void trace_push(NvllmEngine* e, int seq, int logical, int physical) {
+    if (e->trace_len == e->trace_cap) {
+        e->trace_cap = e->trace_cap ? e->trace_cap * 2 : 1024;
+        e->trace = (int*)realloc(e->trace, (size_t)e->trace_cap * 3 * sizeof(int));
+    }
+    int* t = e->trace + 3 * (size_t)e->trace_len++;
+    t[0] = seq; t[1] = logical; t[2] = physical;
+}
+
+NvllmEngine* nvllm_engine_create(const char* model_path, int n_seqs, const NvllmEngineOptions* opt) {
+    if (n_seqs <= 0 || !model_path) return NULL;
+    NvllmEngine* e = (NvllmEngine*)calloc(1, sizeof(NvllmEngine));
+    if (opt) e->opt = *opt;
+    /* clamps of main.c:121-124 */
+    if (e->opt.temperature < 0.0f) e->opt.temperature = 0.0f;
+    if (e->opt.topp < 0.0f || 1.0f < e->opt.topp) e->opt.topp = 0.9f;
+    if (e->opt.chunk_size <= 0) e->opt.chunk_size = INT_MAX;
+    if (e->opt.block_size <= 0) e->opt.block_size = 16;
+    if (e->opt.max_steps <= 0) e->opt.max_steps = 500;
+
+    g_paged_mode = 1;       /* main.c:114-118: paged mode is always on */
+    g_visualize_paged = 1;
+    init_ops();
+    load_model(&e->weights, &e->config, model_path);
+    if (e->opt.max_seq_len > 0) e->config.max_seq_len = e->opt.max_seq_len;
+    if (e->opt.raise_to_1024 && e->config.max_seq_len < 1024) e->config.max_seq_len = 1024; /* main.c:140-143 */
+    malloc_run_state(&e->state, &e->config);
+    e->capacity = e->config.max_seq_len;
+
+    e->n_seqs = n_seqs;
+    e->seqs = (Sequence*)calloc((size_t)n_seqs, sizeof(Sequence));
+    e->history_cap = (int*)calloc((size_t)n_seqs, sizeof(int));
+    const int bs = e->opt.block_size;
+    e->max_blocks_per_seq = (e->config.max_seq_len + bs - 1) / bs;
+    int pool_blocks = e->opt.num_blocks;
+    if (pool_blocks <= 0) pool_blocks = n_seqs * e->max_blocks_per_seq; /* main.c:189-193 */
+    init_kv_cache_manager(&g_kv_manager, bs, pool_blocks, e->config.n_layers, e->config.n_kv_heads,
+                          e->config.head_dim);
+    for (int i = 0; i < n_seqs; i++) {
+        Sequence* s = &e->seqs[i];
+        s->id = i;
+        s->status = SEQ_FINISHED; /* until a request is set */
+        s->table.block_indices = (int*)malloc((size_t)e->max_blocks_per_seq * sizeof(int));
+        s->table.num_blocks = 0;
+    }
+    build_sampler(&e->sampler, e->config.vocab_size, e->opt.temperature, e->opt.topp, e->opt.seed);
+
+    e->batch_tokens = (int*)malloc((size_t)e->capacity * sizeof(int));
+    e->batch_pos = (int*)malloc((size_t)e->capacity * sizeof(int));
+    e->batch_seq_ids = (int*)malloc((size_t)e->capacity * sizeof(int));
+    e->batch_output_indices = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->batch_sampled = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->batch_block_tables = (BlockTable**)malloc((size_t)n_seqs * sizeof(BlockTable*));
+    for (int i = 0; i < n_seqs; i++) e->batch_block_tables[i] = &e->seqs[i].table;
+    return e;
+}
+
+void nvllm_engine_destroy(NvllmEngine* e) {
+    if (!e) return;
+    for (int i = 0; i < e->n_seqs; i++) {
+        free(e->seqs[i].prompt_tokens);
+        free(e->seqs[i].output_history);
+        free(e->seqs[i].table.block_indices);
+    }
+    free(e->seqs);
+    free(e->history_cap);
+    free(e->batch_tokens);
+    free(e->batch_pos);
+    free(e->batch_seq_ids);
+    free(e->batch_output_indices);
+    free(e->batch_sampled);
+    free(e->batch_block_tables);
+    free(e->trace);
+    free(e->sampler.probindex);
+    free_run_state(&e->state);
+    free_ops();
+    free_kv_cache_manager(&g_kv_manager);
+    if (nvllm_free_model) nvllm_free_model(&e->weights);
+    else free(e->weights.layers);
+    free(e);
+}
+
+int nvllm_engine_set_request(NvllmEngine* e, int seq, const int* prompt, int n_prompt, int n_new,
+                             int arrival_step) {
+    if (!e || seq < 0 || seq >= e->n_seqs || n_prompt <= 0 || n_new < 0 || !prompt) return -1;
+    if (n_prompt + n_new > e->config.max_seq_len) return -1; /* block table would overflow */
+    Sequence* s = &e->seqs[seq];
+    free(s->prompt_tokens);
+    free(s->output_history);
+    s->prompt_tokens = (int*)malloc((size_t)n_prompt * sizeof(int));
+    memcpy(s->prompt_tokens, prompt, (size_t)n_prompt * sizeof(int));
+    s->num_prompt_tokens = n_prompt;
+    e->history_cap[seq] = n_prompt + n_new + 1;
+    s->output_history = (int*)calloc((size_t)e->history_cap[seq], sizeof(int));
+    memcpy(s->output_history, prompt, (size_t)n_prompt * sizeof(int)); /* main.c:228-230 */
+    s->active = 0;                        /* main.c:168-174 */
+    s->status = SEQ_WAITING;
+    s->arrival_step = arrival_step;
+    s->pos = 0;
+    s->current_token = prompt[0];         /* main.c:226 */
+    s->seq_len = n_prompt + n_new;        /* main.c:231 */
+    s->table.num_blocks = 0;
+    e->finished = 0;
+    return 0;
+}
+
+static void release_blocks(NvllmEngine* e, Sequence* s) {
+    /* extension: hand a finished sequence's blocks back, last allocated first */
+    for (int b = s->table.num_blocks - 1; b >= 0; b--) free_block(&g_kv_manager, s->table.block_indices[b]);
+    s->table.num_blocks = 0;
+}
+
+int nvllm_engine_step(NvllmEngine* e) {
+    if (!e || e->finished) return 0;
+    int all_finished = 1;
+    int batch_count = 0, output_count = 0;
+    int any_prefill = 0, prefill_tokens = 0, decode_tokens = 0;
+
+    /* scheduler phase (main.c:269-356) */
+    for (int i = 0; i < e->n_seqs; i++) {
+        Sequence* s = &e->seqs[i];
+        if (s->status == SEQ_FINISHED) continue;       /* main.c:284-287 (also: slot unused) */
+        if (e->global_step < s->arrival_step) {        /* main.c:271-275 */
+            all_finished = 0;
+            continue;
+        }
+        if (s->status == SEQ_WAITING) {                /* main.c:278-282 */
+            s->active = 1;
+            s->status = SEQ_PREFILLING;
+        }
+        all_finished = 0;
+
+        const int is_prefill = (s->pos < s->num_prompt_tokens - 1); /* main.c:292 */
+        const int start_pos = s->pos;
+        int n_tokens;
+        const int* token_ptr;
+        if (is_prefill) {
+            s->status = SEQ_PREFILLING;
+            const int remaining = s->num_prompt_tokens - start_pos;
+            n_tokens = remaining > e->opt.chunk_size ? e->opt.chunk_size : remaining;
+            token_ptr = s->prompt_tokens + start_pos;
+        } else {
+            s->status = SEQ_DECODING;
+            n_tokens = 1;
+            token_ptr = &s->current_token;
+        }
+        if (batch_count + n_tokens > e->capacity) continue; /* main.c:315-318 */
+
+        const int bs = g_kv_manager.block_size;             /* main.c:322-335 */
+        for (int t = 0; t < n_tokens; t++) {
+            const int p = start_pos + t;
+            if (p % bs == 0) {
+                const int blk = alloc_block(&g_kv_manager);
+                if (blk == -1) {
+                    printf("Error: Out of KV Cache blocks!\n");
+                    exit(1);
+                }
+                s->table.block_indices[p / bs] = blk;
+                s->table.num_blocks++;
+                trace_push(e, i, p / bs, blk);
+            }
+        }
+        for (int t = 0; t < n_tokens; t++) {                /* main.c:338-342 */
+            e->batch_tokens[batch_count + t] = token_ptr[t];
+            e->batch_pos[batch_count + t] = start_pos + t;
+            e->batch_seq_ids[batch_count + t] = i;
+        }
+        e->batch_output_indices[output_count++] = batch_count + n_tokens - 1; /* main.c:344 */
+        batch_count += n_tokens;
+        s->pos += n_tokens;
+        if (is_prefill) {
+            s->current_token = token_ptr[n_tokens - 1];     /* main.c:353-355 */
+            any_prefill = 1;
+            prefill_tokens += n_tokens;
+        } else {
+            decode_tokens += 1;
+        }
+    }
+
+    if (batch_count == 0 && !all_finished) {                /* main.c:358-362 */
+        e->global_step++;
+        return 1;
+    }
+    if (all_finished) {                                     /* main.c:364 */
+        e->finished = 1;
+        return 0;
+    }
+
+    /* forward pass (main.c:367-369) */
+    const double t0 = now_seconds();
+    transformer_batch(e->batch_tokens, batch_count, e->batch_pos, e->batch_seq_ids,
+                      e->batch_output_indices, output_count, &e->config, &e->state, &e->weights,
+                      e->batch_block_tables);
+    const double t1 = now_seconds();
+
+    /* sampling and bookkeeping (main.c:372-410) */
+    for (int k = 0; k < output_count; k++) {
+        const int sid = e->batch_seq_ids[e->batch_output_indices[k]];
+        Sequence* s = &e->seqs[sid];
+        const int next = sample(&e->sampler, e->state.logits + (size_t)k * e->config.vocab_size);
+        e->batch_sampled[k] = next;
+        if (s->pos >= s->num_prompt_tokens && s->pos < s->seq_len) s->output_history[s->pos] = next;
+        s->current_token = next;
+        if (s->pos >= s->seq_len) {
+            s->active = 0;
+            s->status = SEQ_FINISHED;
+            if (e->opt.recycle_blocks) release_blocks(e, s);
+        }
+    }
+    const double t2 = now_seconds();
+
+    e->last_batch_count = batch_count;
+    e->last_output_count = output_count;
+    e->stats.steps += 1;
+    e->stats.tokens_forwarded += batch_count;
+    e->stats.prefill_tokens += prefill_tokens;
+    e->stats.decode_tokens += decode_tokens;
+    e->stats.outputs += output_count;
+    e->stats.forward_seconds += t1 - t0;
+    e->stats.sample_seconds += t2 - t1;
+    if (any_prefill) {
+        e->stats.prefill_step_seconds += t1 - t0;
+        e->stats.prefill_step_tokens += batch_count;
+    } else {
+        e->stats.decode_step_seconds += t1 - t0;
+        e->stats.decode_step_tokens += batch_count;
+    }
+
+    e->global_step++;
+    if (e->global_step > e->opt.max_steps) {                /* main.c:416-418 */
+        e->finished = 1;
+        return 0;
+    }
+    return 1;
+}
+
+int nvllm_engine_run(NvllmEngine* e, int n) {
+    int ran = 0;
+    while (ran < n) {
+        const int more = nvllm_engine_step(e);
+        ran++;
+        if (!more) break;
+    }
+    return ran;
+}
+
+int nvllm_engine_global_step(const NvllmEngine* e) { return e->global_step; }
+void nvllm_engine_get_stats(const NvllmEngine* e, NvllmEngineStats* out) { *out = e->stats; }
+void nvllm_engine_reset_stats(NvllmEngine* e) { memset(&e->stats, 0, sizeof e->stats); }
+const Config* nvllm_engine_config(const NvllmEngine* e) { return &e->config; }
+
+int nvllm_engine_seq_state(const NvllmEngine* e, int seq, int* status, int* current_token,
+                           int* n_prompt, int* seq_len) {
+    if (seq < 0 || seq >= e->n_seqs) return -1;
+    const Sequence* s = &e->seqs[seq];
+    if (status) *status = (int)s->status;
+    if (current_token) *current_token = s->current_token;
+    if (n_prompt) *n_prompt = s->num_prompt_tokens;
+    if (seq_len) *seq_len = s->seq_len;
+    return s->pos;
+}
+
+int nvllm_engine_history(const NvllmEngine* e, int seq, int* out, int cap) {
+    if (seq < 0 || seq >= e->n_seqs) return -1;
+    const Sequence* s = &e->seqs[seq];
+    int filled = s->pos < s->seq_len ? s->pos : s->seq_len; /* main.c:430-431 */
+    if (!s->output_history) return 0;
+    const int n = filled < cap ? filled : cap;
+    memcpy(out, s->output_history, (size_t)n * sizeof(int));
+    return filled;
+}
+
+int nvllm_engine_block_table(const NvllmEngine* e, int seq, int* out, int cap) {
+    if (seq < 0 || seq >= e->n_seqs) return -1;
+    const BlockTable* bt = &e->seqs[seq].table;
+    const int n = bt->num_blocks < cap ? bt->num_blocks : cap;
+    memcpy(out, bt->block_indices, (size_t)n * sizeof(int));
+    return bt->num_blocks;
+}
+
+int nvllm_engine_last_batch(const NvllmEngine* e, int* tokens, int* pos, int* seq_ids, int cap,
+                            int* output_indices, int* sampled, int out_cap, int* num_outputs) {
+    const int n = e->last_batch_count < cap ? e->last_batch_count : cap;
+    if (tokens) memcpy(tokens, e->batch_tokens, (size_t)n * sizeof(int));
+    if (pos) memcpy(pos, e->batch_pos, (size_t)n * sizeof(int));
+    if (seq_ids) memcpy(seq_ids, e->batch_seq_ids, (size_t)n * sizeof(int));
+    const int m = e->last_output_count < out_cap ? e->last_output_count : out_cap;
+    if (output_indices) memcpy(output_indices, e->batch_output_indices, (size_t)m * sizeof(int));
+    if (sampled) memcpy(sampled, e->batch_sampled, (size_t)m * sizeof(int));
+    if (num_outputs) *num_outputs = e->last_output_count;
+    return e->last_batch_count;
+}
+
+const float* nvllm_engine_logits(const NvllmEngine* e) { return e->state.logits; }
+
+int nvllm_engine_alloc_trace(const NvllmEngine* e, int* out, int cap_triples) {
+    const int n = e->trace_len < cap_triples ? e->trace_len : cap_triples;
+    if (out) memcpy(out, e->trace, (size_t)n * 3 * sizeof(int));
+    return e->trace_len;
+}
