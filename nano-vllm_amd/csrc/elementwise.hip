@@ -1,0 +1,544 @@
+// elementwise.hip -- the memory-bound kernels around the projections: embedding
+// gather, RMSNorm (fp32 and tile-order fp16 output, with the split-K / residual
+// reduction of the preceding projection folded in), RoPE + KV scatter, SwiGLU,
+// residual add, softmax, arg-max and the layout converters.
+#include "nvllm_internal.h"
+
+namespace nvllm {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Block-wide sum for blocks of up to 1024 threads; every thread gets the result.
+__device__ __forceinline__ float block_sum(float v, float* red /*[17]*/) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nw; i++) s += red[i];
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = red[0];
+        for (int i = 1; i < nw; i++) s = fmaxf(s, red[i]);
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+// fp32 -> (hi, lo) fp16 pair with hi + lo == x to ~22 bits.  |x| is clamped to
+// the fp16 range first (activations entering a projection never get near it).
+__device__ __forceinline__ void split16(float x, __half& hi, __half& lo) {
+    const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+    hi = __float2half_rn(c);
+    lo = __float2half_rn(c - __half2float(hi));
+}
+
+struct alignas(16) Half8 {
+    __half v[8];
+};
+
+// offset (in halves) of the 8-element chunk that holds (t, k..k+7), k % 8 == 0
+__device__ __forceinline__ size_t a16_chunk(int t, int k, int Kb, int plane) {
+    const size_t tile = ((size_t)(t >> 4) * Kb + (k >> 5)) * 2 + plane;
+    const int lane = (t & 15) + 16 * ((k >> 3) & 3);
+    return tile * TILE_HALVES + (size_t)lane * 8;
+}
+
+__device__ __forceinline__ void store_a16_8(__half* a16, int t, int k, int Kb, const float* x8) {
+    Half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) split16(x8[j], hi.v[j], lo.v[j]);
+    *reinterpret_cast<Half8*>(a16 + a16_chunk(t, k, Kb, 0)) = hi;
+    *reinterpret_cast<Half8*>(a16 + a16_chunk(t, k, Kb, 1)) = lo;
+}
+
+// ---------------------------------------------------------------- embedding
+// x[t, :] = float(table[tokens[t], :])   (reference model.c:352-355)
+__global__ void k_embed(float* __restrict__ x, const __half* __restrict__ table,
+                        const int* __restrict__ tokens, int D) {
+    const int t = blockIdx.x;
+    const __half* row = table + (size_t)tokens[t] * D;
+    float* dst = x + (size_t)t * D;
+    for (int i = threadIdx.x * 8; i < D; i += blockDim.x * 8) {
+        if (i + 8 <= D) {
+            const Half8 h = *reinterpret_cast<const Half8*>(row + i);
+            float4 a, b;
+            a.x = __half2float(h.v[0]); a.y = __half2float(h.v[1]);
+            a.z = __half2float(h.v[2]); a.w = __half2float(h.v[3]);
+            b.x = __half2float(h.v[4]); b.y = __half2float(h.v[5]);
+            b.z = __half2float(h.v[6]); b.w = __half2float(h.v[7]);
+            *reinterpret_cast<float4*>(dst + i) = a;
+            *reinterpret_cast<float4*>(dst + i + 4) = b;
+        } else {
+            for (int j = i; j < D; j++) dst[j] = __half2float(row[j]);
+        }
+    }
+}
+
+void launch_embed(float* x, const __half* table, const int* tokens, int T, int D) {
+    if (T <= 0) return;
+    if (D % 8) NVLLM_FATAL("embedding width %d is not a multiple of 8", D);
+    ProfScope ps(PC_EMBED, (double)T * D * 6, 0);
+    hipLaunchKernelGGL(k_embed, dim3(T), dim3(256), 0, rt().stream, x, table, tokens, D);
+}
+
+// ------------------------------------------------------------------ RMSNorm
+// One workgroup per output row.  Pass 1: (optionally) fold in the split-K slabs of
+// the previous projection, x += sum_s slab[s], and accumulate the sum of squares;
+// pass 2: re-read the thread's own elements (L1/L2-hot) and write the normalised
+// row, either fp32 row-major or fp16 hi/lo tiles.
+// Arithmetic per element as reference layers.c:32-35: r = 1/sqrtf(ss/D + eps),
+// out = (x * r) * g.
+template <bool A16OUT>
+__global__ __launch_bounds__(256) void k_rmsnorm(float* out_f32, __half* out_a16, float* x,
+                                                 const float* __restrict__ gain,
+                                                 const float* __restrict__ slabs, int ksplit,
+                                                 long slab_stride, int D, float eps,
+                                                 const int* __restrict__ gather) {
+    __shared__ float red[17];
+    const int r = blockIdx.x;
+    const int ts = gather ? gather[r] : r;
+    float* xr = x + (size_t)ts * D;
+    float ss = 0.f;
+    for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
+        float4 v = *reinterpret_cast<const float4*>(xr + i);
+        if (ksplit > 0) {
+            for (int s = 0; s < ksplit; s++) {
+                const float4 p = *reinterpret_cast<const float4*>(slabs + s * slab_stride + (size_t)ts * D + i);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            // pass 2 re-reads the row, so the folded sum goes back to x in every mode
+            // (rows named twice by `gather` would race; output rows are distinct)
+            *reinterpret_cast<float4*>(xr + i) = v;
+        }
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = block_sum(ss, red);
+    const float rinv = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)D), eps)));
+    const int Kb = (D + 31) >> 5;
+    if (A16OUT) {
+        for (int i = threadIdx.x * 8; i < Kb * 32; i += blockDim.x * 8) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = i + j;
+                y[j] = c < D ? __fmul_rn(__fmul_rn(xr[c], rinv), gain[c]) : 0.f;
+            }
+            store_a16_8(out_a16, r, i, Kb, y);
+        }
+    } else {
+        float* o = out_f32 + (size_t)r * D;
+        for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + i);
+            const float4 g = *reinterpret_cast<const float4*>(gain + i);
+            float4 y;
+            y.x = __fmul_rn(__fmul_rn(v.x, rinv), g.x);
+            y.y = __fmul_rn(__fmul_rn(v.y, rinv), g.y);
+            y.z = __fmul_rn(__fmul_rn(v.z, rinv), g.z);
+            y.w = __fmul_rn(__fmul_rn(v.w, rinv), g.w);
+            *reinterpret_cast<float4*>(o + i) = y;
+        }
+    }
+}
+
+// generic width (not a multiple of 4): scalar loops, fp32 output only
+__global__ __launch_bounds__(256) void k_rmsnorm_any(float* out, const float* x,
+                                                     const float* __restrict__ gain, int D, float eps) {
+    __shared__ float red[17];
+    const float* xr = x + (size_t)blockIdx.x * D;
+    float* o = out + (size_t)blockIdx.x * D;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) ss += xr[i] * xr[i];
+    ss = block_sum(ss, red);
+    const float rinv = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)D), eps)));
+    for (int i = threadIdx.x; i < D; i += blockDim.x) o[i] = __fmul_rn(__fmul_rn(xr[i], rinv), gain[i]);
+}
+
+void launch_rmsnorm_a16(__half* a16, float* x, const float* gain, const float* slabs, int ksplit,
+                        int Tpad, int T, int D, float eps, const int* gather, int prof_cls) {
+    if (T <= 0) return;
+    if (D % 4) NVLLM_FATAL("fused RMSNorm needs a width that is a multiple of 4, got %d", D);
+    ProfScope ps(prof_cls, (double)T * D * (4.0 * (2 + ksplit) + 4.0), 0);
+    hipLaunchKernelGGL(k_rmsnorm<true>, dim3(T), dim3(256), 0, rt().stream, (float*)nullptr, a16, x, gain,
+                       slabs, ksplit, (long)Tpad * D, D, eps, gather);
+}
+
+void launch_rmsnorm_f32(float* o, const float* x, const float* gain, int D, int T, float eps) {
+    if (T <= 0) return;
+    ProfScope ps(PC_RMSNORM, (double)T * D * 8.0, 0);
+    if (D % 4 == 0 && ((uintptr_t)o % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)gain % 16 == 0))
+        hipLaunchKernelGGL(k_rmsnorm<false>, dim3(T), dim3(256), 0, rt().stream, o, (__half*)nullptr,
+                           const_cast<float*>(x), gain, (const float*)nullptr, 0, 0L, D, eps,
+                           (const int*)nullptr);
+    else
+        hipLaunchKernelGGL(k_rmsnorm_any, dim3(T), dim3(256), 0, rt().stream, o, x, gain, D, eps);
+}
+
+// -------------------------------------------------------------- pack to a16
+__global__ __launch_bounds__(256) void k_pack_a16(__half* __restrict__ a16, const float* __restrict__ in,
+                                                  int T, int K, int Kb, int Tb) {
+    // one thread per (tile, lane): 8 consecutive k of one token
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)Tb * Kb * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long tile = idx >> 6;
+    const int kb = (int)(tile % Kb), tb = (int)(tile / Kb);
+    const int t = tb * 16 + (lane & 15);
+    const int k = kb * 32 + 8 * (lane >> 4);
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) y[j] = (t < T && k + j < K) ? in[(size_t)t * K + k + j] : 0.f;
+    store_a16_8(a16, t, k, Kb, y);
+}
+
+void launch_pack_a16(__half* a16, const float* in, int T, int K) {
+    if (T <= 0) return;
+    const int Kb = cdiv(K, 32), Tb = cdiv(T, 16);
+    const long total = (long)Tb * Kb * 64;
+    ProfScope ps(PC_PACK, (double)T * K * 8.0, 0);
+    hipLaunchKernelGGL(k_pack_a16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rt().stream, a16, in,
+                       T, K, Kb, Tb);
+}
+
+// ------------------------------------------------------------- slab reduce
+__global__ void k_slab_reduce(float* out, const float* __restrict__ slabs, int ksplit, long slab_stride,
+                              long n, const float* residual) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = residual ? residual[i] : 0.f;
+        for (int s = 0; s < ksplit; s++) v += slabs[s * slab_stride + i];
+        out[i] = v;
+    }
+}
+
+void launch_slab_reduce(float* out, const float* slabs, int ksplit, int T, int Tpad, int N,
+                        const float* residual) {
+    const long n = (long)T * N;
+    if (n <= 0) return;
+    ProfScope ps(PC_ELEMWISE, (double)n * 4.0 * (ksplit + 1 + (residual ? 1 : 0)), 0);
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, rt().stream, out, slabs, ksplit,
+                       (long)Tpad * N, n, residual);
+}
+
+// --------------------------------------------------------------------- RoPE
+// Rotation of one interleaved pair with the reference's rounding
+// (layers.c:129-130): two products, one subtraction/addition, no fused multiply-add.
+__device__ __forceinline__ float2 rot(float a, float b, float2 cs) {
+    float2 r;
+    r.x = __fsub_rn(__fmul_rn(a, cs.x), __fmul_rn(b, cs.y));
+    r.y = __fadd_rn(__fmul_rn(a, cs.y), __fmul_rn(b, cs.x));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_rope(float* q, float* k, const int* __restrict__ pos, int pos0,
+                                              const float2* __restrict__ rope, int H, int KVH, int hd) {
+    const int t = blockIdx.x;
+    const int p = pos ? pos[t] : pos0 + t;
+    const int half = hd >> 1;
+    const float2* tab = rope + (size_t)p * half;
+    float* qr = q + (size_t)t * H * hd;
+    float* kr = k + (size_t)t * KVH * hd;
+    for (int i = threadIdx.x; i < H * half; i += blockDim.x) {
+        float2* pr = reinterpret_cast<float2*>(qr) + i;
+        const float2 v = *pr;
+        *pr = rot(v.x, v.y, tab[i % half]);
+    }
+    for (int i = threadIdx.x; i < KVH * half; i += blockDim.x) {
+        float2* pr = reinterpret_cast<float2*>(kr) + i;
+        const float2 v = *pr;
+        *pr = rot(v.x, v.y, tab[i % half]);
+    }
+}
+
+void launch_rope(float* q, float* k, const int* pos, int pos0, const float2* rope, int T, int H, int KVH,
+                 int hd) {
+    if (T <= 0) return;
+    ProfScope ps(PC_ROPE_KV, (double)T * (H + KVH) * hd * 8.0, 0);
+    hipLaunchKernelGGL(k_rope, dim3(T), dim3(256), 0, rt().stream, q, k, pos, pos0, rope, H, KVH, hd);
+}
+
+// Physical row (in units of token rows) of position p of the sequence that owns
+// `table`; a null table means a contiguous cache.
+__device__ __forceinline__ long kv_row(const int* table, int p, int bs) {
+    return table ? (long)table[p / bs] * bs + (p % bs) : (long)p;
+}
+
+template <typename KVT>
+__device__ __forceinline__ void kv_store2(KVT* dst, float a, float b);
+template <>
+__device__ __forceinline__ void kv_store2<float>(float* dst, float a, float b) {
+    *reinterpret_cast<float2*>(dst) = make_float2(a, b);
+}
+template <>
+__device__ __forceinline__ void kv_store2<__half>(__half* dst, float a, float b) {
+    *reinterpret_cast<__half2*>(dst) = __halves2half2(__float2half_rn(a), __float2half_rn(b));
+}
+
+// Fused: q,k,v = sum of the projection's split-K slabs; rotate q and k; store q as
+// fp32 rows and scatter k,v into the block pool (reference model.c:363-377).
+template <typename KVT>
+__global__ __launch_bounds__(256) void k_rope_kv(float* __restrict__ q_out, float* __restrict__ k_out,
+                                                 float* __restrict__ v_out,
+                                                 const float* __restrict__ slabs, int ksplit,
+                                                 long slab_stride, int H, int KVH, int hd,
+                                                 const int* __restrict__ pos, const int* __restrict__ seq,
+                                                 const int* __restrict__ tbl_off,
+                                                 const int* __restrict__ tables,
+                                                 const float2* __restrict__ rope, KVT* pool_k, KVT* pool_v,
+                                                 int bs, long layer_off, int write_limit) {
+    const int t = blockIdx.x;
+    const int p = pos[t];
+    const int half = hd >> 1;
+    const int QD = H * hd, KD = KVH * hd, ND = QD + 2 * KD;
+    const float2* tab = rope + (size_t)p * half;
+    const float* src = slabs + (size_t)t * ND;
+    const int* table = tables + tbl_off[seq[t]];
+    const bool store_kv = t < write_limit;
+    const long row = store_kv ? kv_row(table, p, bs) : 0;
+    KVT* kd = pool_k + layer_off + row * KD;
+    KVT* vd = pool_v + layer_off + row * KD;
+    for (int i = threadIdx.x; i < ND / 2; i += blockDim.x) {
+        float2 v = reinterpret_cast<const float2*>(src)[i];
+        for (int s = 1; s < ksplit; s++) {
+            const float2 w = reinterpret_cast<const float2*>(src + s * slab_stride)[i];
+            v.x += w.x;
+            v.y += w.y;
+        }
+        const int e = 2 * i;
+        if (e < QD) {
+            const float2 r = rot(v.x, v.y, tab[i % half]);
+            reinterpret_cast<float2*>(q_out + (size_t)t * QD)[i] = r;
+        } else if (e < QD + KD) {
+            const int j = i - QD / 2;
+            const float2 r = rot(v.x, v.y, tab[j % half]);
+            if (k_out) reinterpret_cast<float2*>(k_out + (size_t)t * KD)[j] = r;
+            if (store_kv) kv_store2<KVT>(kd + 2 * j, r.x, r.y);
+        } else {
+            const int j = i - (QD + KD) / 2;
+            if (v_out) reinterpret_cast<float2*>(v_out + (size_t)t * KD)[j] = v;
+            if (store_kv) kv_store2<KVT>(vd + 2 * j, v.x, v.y);
+        }
+    }
+}
+
+void launch_rope_kv(float* q, float* k, float* v, const float* slabs, int ksplit, int Tpad, int T, int H,
+                    int KVH, int hd, const int* pos, const int* seq, const int* tbl_off, const int* tables,
+                    const float2* rope, const KvPoolView& pool, int layer, int write_limit) {
+    if (T <= 0) return;
+    const int ND = (H + 2 * KVH) * hd;
+    ProfScope ps(PC_ROPE_KV, (double)T * ND * 4.0 * (ksplit + 1), 0);
+    const long slab_stride = (long)Tpad * ND;
+    const long layer_off = (long)layer * pool.layer_stride;
+    if (pool.elem_bytes == 4)
+        hipLaunchKernelGGL(k_rope_kv<float>, dim3(T), dim3(256), 0, rt().stream, q, k, v, slabs, ksplit,
+                           slab_stride, H, KVH, hd, pos, seq, tbl_off, tables, rope, (float*)pool.k,
+                           (float*)pool.v, pool.block_size, layer_off, write_limit);
+    else
+        hipLaunchKernelGGL(k_rope_kv<__half>, dim3(T), dim3(256), 0, rt().stream, q, k, v, slabs, ksplit,
+                           slab_stride, H, KVH, hd, pos, seq, tbl_off, tables, rope, (__half*)pool.k,
+                           (__half*)pool.v, pool.block_size, layer_off, write_limit);
+}
+
+// Plain scatter of K/V rows (reference attention.c:11-30, :109-175).
+template <typename KVT>
+__global__ __launch_bounds__(256) void k_kv_write(const float* __restrict__ k, const float* __restrict__ v,
+                                                  const int* __restrict__ pos, int pos0,
+                                                  const int* __restrict__ seq,
+                                                  const int* __restrict__ tbl_off,
+                                                  const int* __restrict__ tables, KVT* pool_k, KVT* pool_v,
+                                                  int bs, long layer_off, int KD) {
+    const int t = blockIdx.x;
+    const int p = pos ? pos[t] : pos0 + t;
+    const int* table = tables ? tables + (seq ? tbl_off[seq[t]] : 0) : nullptr;
+    const long row = kv_row(table, p, bs);
+    KVT* kd = pool_k + layer_off + row * KD;
+    KVT* vd = pool_v + layer_off + row * KD;
+    const float* ks = k + (size_t)t * KD;
+    const float* vs = v + (size_t)t * KD;
+    for (int i = threadIdx.x; i < KD / 2; i += blockDim.x) {
+        const float2 a = reinterpret_cast<const float2*>(ks)[i];
+        const float2 b = reinterpret_cast<const float2*>(vs)[i];
+        kv_store2<KVT>(kd + 2 * i, a.x, a.y);
+        kv_store2<KVT>(vd + 2 * i, b.x, b.y);
+    }
+}
+
+void launch_kv_write(const float* k, const float* v, const int* pos, int pos0, const int* seq,
+                     const int* tbl_off, const int* tables, const KvPoolView& pool, int layer, int T, int KVH,
+                     int hd) {
+    if (T <= 0) return;
+    const int KD = KVH * hd;
+    if (KD % 2) NVLLM_FATAL("KV row width %d must be even", KD);
+    ProfScope ps(PC_ROPE_KV, (double)T * KD * 2 * (4.0 + pool.elem_bytes), 0);
+    const long layer_off = (long)layer * pool.layer_stride;
+    if (pool.elem_bytes == 4)
+        hipLaunchKernelGGL(k_kv_write<float>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
+                           tables, (float*)pool.k, (float*)pool.v, pool.block_size, layer_off, KD);
+    else
+        hipLaunchKernelGGL(k_kv_write<__half>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
+                           tables, (__half*)pool.k, (__half*)pool.v, pool.block_size, layer_off, KD);
+}
+
+// ------------------------------------------------------------- small ops
+// silu(g) * u with the reference's operation order (layers.c:156-158).
+__device__ __forceinline__ float swiglu1(float g, float u) {
+    const float act = __fdiv_rn(g, __fadd_rn(1.0f, expf(-g)));
+    return __fmul_rn(act, u);
+}
+
+__global__ void k_swiglu(float* out, const float* g, const float* u, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = swiglu1(g[i], u[i]);
+}
+void launch_swiglu(float* out, const float* g, const float* u, long n) {
+    if (n <= 0) return;
+    ProfScope ps(PC_ELEMWISE, (double)n * 12.0, 0);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_swiglu, dim3(blocks), dim3(256), 0, rt().stream, out, g, u, n);
+}
+
+__global__ void k_accum(float* a, const float* b, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        a[i] = __fadd_rn(a[i], b[i]);
+}
+void launch_accum(float* a, const float* b, long n) {
+    if (n <= 0) return;
+    ProfScope ps(PC_ELEMWISE, (double)n * 12.0, 0);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_accum, dim3(blocks), dim3(256), 0, rt().stream, a, b, n);
+}
+
+// softmax of one vector (reference layers.c:170-186): max, exp+sum, divide
+__global__ __launch_bounds__(1024) void k_softmax(float* x, int n) {
+    __shared__ float red[17];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, x[i]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = expf(x[i] - m);
+        x[i] = e;
+        s += e;
+    }
+    s = block_sum(s, red);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = __fdiv_rn(x[i], s);
+}
+void launch_softmax(float* x, int n) {
+    if (n <= 0) return;
+    ProfScope ps(PC_ELEMWISE, (double)n * 16.0, 0);
+    hipLaunchKernelGGL(k_softmax, dim3(1), dim3(1024), 0, rt().stream, x, n);
+}
+
+// First index of the row maximum (reference sampler.c:86-97: strict '>' scan, so
+// ties resolve to the lowest index).
+__global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const float* __restrict__ logits, int V) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const float* row = logits + (size_t)blockIdx.x * V;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = row[i];
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sv[wid] = best;
+        si[wid] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+                best = sv[w];
+                bi = si[w];
+            }
+        // a row of -inf (or NaN in slot 0) leaves the scan at index 0 in the reference
+        out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+void launch_argmax(int* out, const float* logits, int B, int V) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
+    hipLaunchKernelGGL(k_argmax, dim3(B), dim3(1024), 0, rt().stream, out, logits, V);
+}
+
+// ------------------------------------------------------ layout converters
+// row-major fp16 [N, K] -> tile order, zero padded to whole tiles
+__global__ __launch_bounds__(256) void k_tile_weights(__half* __restrict__ tiles,
+                                                      const __half* __restrict__ rm, int N, int K, int Kb,
+                                                      int Nb, long nb_stride) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)Nb * Kb * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long tile = idx >> 6;
+    const int kb = (int)(tile % Kb), nb = (int)(tile / Kb);
+    const int n = nb * 16 + (lane & 15);
+    const int k = kb * 32 + 8 * (lane >> 4);
+    Half8 h;
+#pragma unroll
+    for (int j = 0; j < 8; j++) h.v[j] = (n < N && k + j < K) ? rm[(size_t)n * K + k + j] : __float2half(0.f);
+    *reinterpret_cast<Half8*>(tiles + (size_t)nb * nb_stride + (size_t)kb * TILE_HALVES + lane * 8) = h;
+}
+void launch_tile_weights(__half* tiles, const __half* rowmajor, int N, int K, long nb_stride) {
+    const int Kb = cdiv(K, 32), Nb = cdiv(N, 16);
+    const long total = (long)Nb * Kb * 64;
+    hipLaunchKernelGGL(k_tile_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rt().stream, tiles,
+                       rowmajor, N, K, Kb, Nb, nb_stride);
+}
+
+__global__ void k_f32_to_f16(__half* dst, const float* src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __float2half_rn(src[i]);
+}
+void launch_f32_to_f16(__half* dst, const float* src, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_f32_to_f16, dim3(2048), dim3(256), 0, rt().stream, dst, src, n);
+}
+__global__ void k_f16_to_f32(float* dst, const __half* src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = __half2float(src[i]);
+}
+void launch_f16_to_f32(float* dst, const __half* src, size_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_f16_to_f32, dim3(2048), dim3(256), 0, rt().stream, dst, src, n);
+}
+
+}  // namespace nvllm

@@ -1,0 +1,419 @@
+// model.hip -- include/model.h on the GPU: the model file goes to HBM as fp16 in
+// tile order, the per-call workspace is allocated once, and transformer_batch
+// enqueues the fused per-layer kernel sequence and hands back logits / arg-max.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "nvllm_internal.h"
+#include "step_arrays.h"
+
+// The driver owns these (reference src/main.c:51-55); engine.c holds weak
+// fall-back definitions for when the library runs without that driver.
+extern "C" {
+extern int g_paged_mode;
+extern KVCacheManager g_kv_manager;
+void* nvllm_internal_pinned_alloc(size_t bytes);
+}
+
+namespace nvllm {
+
+struct LayerPriv {
+    const __half* qkv;     // tiles of [QD + 2*KD, D]: wq rows, then wk, then wv
+    const __half* wo;      // tiles of [D, QD]
+    const __half* gateup;  // tiles of [2F, D], 16-row blocks alternating gate, up
+    const __half* down;    // tiles of [D, F]
+    const float* rms_att;
+    const float* rms_ffn;
+};
+
+struct ModelPriv {
+    Config cfg;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    const __half* embed = nullptr;   // [V, D] row-major fp16
+    const __half* head = nullptr;    // tiles of [V, D]
+    const float* rms_final = nullptr;
+    std::vector<LayerPriv> layers;
+    std::vector<const void*> handles;
+};
+
+// State of the most recent forward pass, for sample() and nvllm_last_argmax().
+static int* g_argmax_host = nullptr;   // pinned
+static int g_argmax_cap = 0;
+static int g_last_outputs = 0;
+static const float* g_last_logits_host = nullptr;
+static const float* g_last_logits_dev = nullptr;
+static int g_last_vocab = 0;
+
+static void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
+    if (fread(dst, 1, bytes, f) != bytes) {
+        fprintf(stderr, "Failed to read %s from file (expected %zu bytes)\n", what, bytes);
+        exit(1);
+    }
+}
+
+}  // namespace nvllm
+
+using namespace nvllm;
+
+extern "C" {
+
+// ------------------------------------------------------------- load_model
+// File format and tensor order: reference src/model.c:118-279.
+void load_model(Weights* w, Config* p, const char* checkpoint_path) {
+    ensure_init();
+    FILE* f = fopen(checkpoint_path, "rb");
+    if (!f) {
+        fprintf(stderr, "Failed to open model file: %s\n", checkpoint_path);
+        exit(1);
+    }
+    if (fread(p, sizeof(int), 7, f) != 7) exit(1);
+    const long header = ftell(f);
+    fseek(f, 0, SEEK_END);
+    const long long payload = ftell(f) - header;
+    fseek(f, header, SEEK_SET);
+    if (p->dim <= 0 || p->n_heads <= 0 || p->n_kv_heads <= 0 || p->dim % p->n_heads != 0 ||
+        p->n_heads % p->n_kv_heads != 0) {
+        fprintf(stderr, "model header is inconsistent (dim %d, heads %d/%d)\n", p->dim, p->n_heads, p->n_kv_heads);
+        exit(1);
+    }
+    p->head_dim = p->dim / p->n_heads;  // model.c:144
+    p->rope_theta = 10000.0f;           // model.c:146
+
+    const long long D = p->dim, F = p->hidden_dim, L = p->n_layers, V = p->vocab_size;
+    const long long QD = (long long)p->n_heads * p->head_dim, KD = (long long)p->n_kv_heads * p->head_dim;
+    const long long body = V * D + L * (2 * D + D * QD + 2 * D * KD + QD * D + 3 * D * F) + D;
+    const long long headw = V * D;
+    const long long rope_tail = (long long)p->max_seq_len * p->head_dim * 4;
+    int fp32, shared;  // size-based detection, model.c:187-220
+    if (payload == body * 4 || payload == body * 4 + rope_tail) { fp32 = 1; shared = 1; }
+    else if (payload == (body + headw) * 4)                     { fp32 = 1; shared = 0; }
+    else if (payload == (body + headw) * 2)                     { fp32 = 0; shared = 0; }
+    else if (payload == body * 2)                               { fp32 = 0; shared = 1; }
+    else {
+        printf("Warning: File size matches none of the expected formats! Trying FP16 Unshared as fallback...\n");
+        fp32 = 0; shared = 0;
+    }
+    if (D % 32 || F % 32 || QD % 32 || KD % 16 || p->head_dim % 8) {
+        fprintf(stderr, "unsupported shape: dim %lld, hidden %lld, q width %lld must be multiples of 32, kv width %lld of 16, head_dim %d of 8\n",
+                D, F, QD, KD, p->head_dim);
+        exit(1);
+    }
+    if (fp32) printf("nvllm: fp32 checkpoint: matrices are rounded to fp16 for HBM residency\n");
+
+    ModelPriv* m = new ModelPriv();
+    m->cfg = *p;
+    // ---- arena plan (all offsets 256-byte aligned)
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t Kb_D = D / 32, Kb_QD = QD / 32, Kb_F = F / 32;
+    const size_t t_qkv = (size_t)((QD + 2 * KD) / 16) * Kb_D * TILE_HALVES * 2;
+    const size_t t_wo = (size_t)(D / 16) * Kb_QD * TILE_HALVES * 2;
+    const size_t t_gu = (size_t)(2 * F / 16) * Kb_D * TILE_HALVES * 2;
+    const size_t t_dn = (size_t)(D / 16) * Kb_F * TILE_HALVES * 2;
+    const size_t t_head = (size_t)((V + 15) / 16) * Kb_D * TILE_HALVES * 2;
+    const size_t per_layer = align(t_qkv) + align(t_wo) + align(t_gu) + align(t_dn) + 2 * align(D * 4);
+    const size_t total = align(V * D * 2) + L * per_layer + align(D * 4) + align(t_head);
+    if (device_malloc(&m->arena, total) != 0) NVLLM_FATAL("cannot allocate %zu bytes of HBM for the weights", total);
+    m->arena_bytes = total;
+    char* base = (char*)m->arena;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* q = base + off; off += align(bytes); return q; };
+    m->embed = (const __half*)carve(V * D * 2);
+    m->layers.resize(L);
+    for (int l = 0; l < L; l++) {
+        LayerPriv& lp = m->layers[l];
+        lp.qkv = (const __half*)carve(t_qkv);
+        lp.wo = (const __half*)carve(t_wo);
+        lp.gateup = (const __half*)carve(t_gu);
+        lp.down = (const __half*)carve(t_dn);
+        lp.rms_att = (const float*)carve(D * 4);
+        lp.rms_ffn = (const float*)carve(D * 4);
+    }
+    m->rms_final = (const float*)carve(D * 4);
+    m->head = (const __half*)carve(t_head);
+
+    // ---- stream the file through one host buffer and one HBM staging buffer
+    const size_t biggest = (size_t)std::max<long long>(std::max(V * D, D * F), D * QD);
+    const size_t esz = fp32 ? 4 : 2;
+    void* host = malloc(biggest * esz);
+    void* stage = nullptr;       // raw file elements
+    __half* stage16 = nullptr;   // fp16 row-major (== stage for fp16 files)
+    if (!host || device_malloc(&stage, biggest * esz) != 0) NVLLM_FATAL("no memory for the %zu-byte load buffer", biggest * esz);
+    if (fp32) {
+        void* s16 = nullptr;
+        if (device_malloc(&s16, biggest * 2) != 0) NVLLM_FATAL("no memory for the fp16 staging buffer");
+        stage16 = (__half*)s16;
+    } else {
+        stage16 = (__half*)stage;
+    }
+    hipStream_t st = rt().stream;
+    auto fetch = [&](size_t n, const char* what) {  // file -> stage16 (fp16 row-major on device)
+        read_exact(f, host, n * esz, what);
+        HIP_CHECK(hipMemcpyAsync(stage, host, n * esz, hipMemcpyHostToDevice, st));
+        if (fp32) launch_f32_to_f16(stage16, (const float*)stage, n);
+        HIP_CHECK(hipStreamSynchronize(st));  // `host` is reused by the next tensor
+    };
+    auto fetch_vec = [&](const float* dst, size_t n, const char* what) {  // norm gains stay fp32
+        read_exact(f, host, n * esz, what);
+        HIP_CHECK(hipMemcpyAsync(stage, host, n * esz, hipMemcpyHostToDevice, st));
+        if (fp32) HIP_CHECK(hipMemcpyAsync((void*)dst, stage, n * 4, hipMemcpyDeviceToDevice, st));
+        else launch_f16_to_f32((float*)dst, (const __half*)stage, n);
+        HIP_CHECK(hipStreamSynchronize(st));
+    };
+    auto tile_into = [&](const __half* dst, long long rows, long long K, long nb_stride) {
+        launch_tile_weights(const_cast<__half*>(dst), stage16, (int)rows, (int)K, nb_stride);
+        HIP_CHECK(hipStreamSynchronize(st));
+    };
+    const long str_D = (long)Kb_D * TILE_HALVES, str_QD = (long)Kb_QD * TILE_HALVES, str_F = (long)Kb_F * TILE_HALVES;
+
+    fetch(V * D, "token_embedding_table");
+    HIP_CHECK(hipMemcpyAsync((void*)m->embed, stage16, V * D * 2, hipMemcpyDeviceToDevice, st));
+    if (shared) tile_into(m->head, V, D, str_D);
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int l = 0; l < L; l++) fetch_vec(m->layers[l].rms_att, D, "rms_att_weight");
+    for (int l = 0; l < L; l++) { fetch(D * QD, "wq"); tile_into(m->layers[l].qkv, QD, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch(D * KD, "wk"); tile_into(m->layers[l].qkv + (QD / 16) * str_D, KD, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch(D * KD, "wv"); tile_into(m->layers[l].qkv + ((QD + KD) / 16) * str_D, KD, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch(QD * D, "wo"); tile_into(m->layers[l].wo, D, QD, str_QD); }
+    for (int l = 0; l < L; l++) fetch_vec(m->layers[l].rms_ffn, D, "rms_ffn_weight");
+    for (int l = 0; l < L; l++) { fetch(D * F, "w_gate"); tile_into(m->layers[l].gateup, F, D, 2 * str_D); }
+    for (int l = 0; l < L; l++) { fetch(F * D, "w_down"); tile_into(m->layers[l].down, D, F, str_F); }  // file order: down before up (model.c:262-269)
+    for (int l = 0; l < L; l++) { fetch(D * F, "w_up"); tile_into(m->layers[l].gateup + str_D, F, D, 2 * str_D); }
+    fetch_vec(m->rms_final, D, "rms_final_weight");
+    if (!shared) { fetch(V * D, "lm_head"); tile_into(m->head, V, D, str_D); }
+    fclose(f);
+    free(host);
+    device_free(stage);
+    if (fp32) device_free(stage16);
+
+    // ---- public handles
+    w->layers = (LayerWeights*)malloc((size_t)L * sizeof(LayerWeights));
+    auto reg = [&](const __half* tiles, long long N, long long K, long nb_stride) -> float* {
+        WeightEntry e{tiles, (int)N, (int)K, (int)(K / 32), nb_stride, nullptr};
+        register_weight(tiles, e);
+        m->handles.push_back(tiles);
+        return (float*)tiles;
+    };
+    for (int l = 0; l < L; l++) {
+        LayerPriv& lp = m->layers[l];
+        LayerWeights& lw = w->layers[l];
+        lw.rms_att_weight = (float*)lp.rms_att;
+        lw.wq = reg(lp.qkv, QD, D, str_D);
+        lw.wk = reg(lp.qkv + (QD / 16) * str_D, KD, D, str_D);
+        lw.wv = reg(lp.qkv + ((QD + KD) / 16) * str_D, KD, D, str_D);
+        lw.wo = reg(lp.wo, D, QD, str_QD);
+        lw.rms_ffn_weight = (float*)lp.rms_ffn;
+        lw.w_gate = reg(lp.gateup, F, D, 2 * str_D);
+        lw.w_up = reg(lp.gateup + str_D, F, D, 2 * str_D);
+        lw.w_down = reg(lp.down, D, F, str_F);
+    }
+    {
+        WeightEntry e{nullptr, (int)V, (int)D, (int)Kb_D, 0, m->embed};
+        register_weight(m->embed, e);
+        m->handles.push_back(m->embed);
+    }
+    w->token_embedding_table = (float*)m->embed;
+    w->rms_final_weight = (float*)m->rms_final;
+    w->lm_head = reg(m->head, V, D, str_D);
+    w->_data_buffer = m;
+}
+
+void nvllm_free_model(Weights* w) {
+    if (!w || !w->_data_buffer) return;
+    ModelPriv* m = (ModelPriv*)w->_data_buffer;
+    for (const void* h : m->handles) unregister_weight(h);
+    device_free(m->arena);
+    delete m;
+    free(w->layers);
+    memset(w, 0, sizeof *w);
+}
+
+// ------------------------------------------------------------- workspace
+// Reference src/model.c:287-336.  Same buffers, same capacities; `logits` is
+// page-locked host memory (the driver reads it, the sampler rewrites it).
+void malloc_run_state(RunState* s, Config* p) {
+    ensure_init();
+    const size_t S = (size_t)p->max_seq_len, D = p->dim, F = p->hidden_dim;
+    auto dev = [&](size_t floats) {
+        void* q = nullptr;
+        if (device_malloc(&q, floats * sizeof(float)) != 0) NVLLM_FATAL("cannot allocate %zu floats of workspace", floats);
+        return (float*)q;
+    };
+    s->x = dev(S * D);
+    s->xb = dev(S * D);
+    s->xb2 = dev(S * D);
+    s->hb = dev(S * F);
+    s->hb2 = dev(S * F);
+    s->q = dev(S * D);
+    s->k = dev(S * D);
+    s->v = dev(S * D);
+    s->att = dev((size_t)p->n_heads * S);
+    s->logits = (float*)nvllm_internal_pinned_alloc(S * (size_t)p->vocab_size * sizeof(float));
+    s->key_cache = s->value_cache = nullptr;
+    if (!g_paged_mode) {
+        const size_t n = (size_t)p->n_layers * S * p->n_kv_heads * p->head_dim;
+        s->key_cache = dev(n);
+        s->value_cache = dev(n);
+    }
+}
+
+void free_run_state(RunState* s) {
+    device_free(s->x); device_free(s->xb); device_free(s->xb2); device_free(s->hb); device_free(s->hb2);
+    device_free(s->q); device_free(s->k); device_free(s->v); device_free(s->att); device_free(s->logits);
+    if (s->key_cache) device_free(s->key_cache);
+    if (s->value_cache) device_free(s->value_cache);
+    memset(s, 0, sizeof *s);
+    g_last_logits_host = nullptr;
+}
+
+void transformer(int* tokens, int num_tokens, int pos, Config* p, RunState* s, Weights* w, BlockTable* bt) {
+    (void)tokens; (void)num_tokens; (void)pos; (void)p; (void)s; (void)w; (void)bt;
+    printf("Error: Old transformer called in Continuous Batching mode.\n");  // model.c:342
+    exit(1);
+}
+
+// ------------------------------------------------------- transformer_batch
+void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
+                       int num_outputs, Config* p, RunState* s, Weights* w, BlockTable** block_tables) {
+    ensure_init();
+    if (!g_paged_mode) {  // model.c:374-377
+        printf("Error: Continuous batching requires paged mode.\n");
+        exit(1);
+    }
+    ModelPriv* m = (ModelPriv*)w->_data_buffer;
+    if (!m) NVLLM_FATAL("transformer_batch: these weights were not produced by this library's load_model");
+    const int T = num_tokens, B = num_outputs;
+    if (T <= 0) return;
+    if (T > p->max_seq_len || B > p->max_seq_len) NVLLM_FATAL("batch of %d tokens exceeds the workspace (%d)", T, p->max_seq_len);
+    const int D = p->dim, F = p->hidden_dim, hd = p->head_dim, H = p->n_heads, KVH = p->n_kv_heads;
+    const int QD = H * hd, KD = KVH * hd, V = p->vocab_size;
+    const int Tpad = cdiv(T, 16) * 16;
+    const float eps = 1e-5f;  // model.c:361,388,396
+
+    StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
+                               g_kv_manager.block_size);
+    const float2* rope = rope_table(p->rope_theta, hd, st.max_pos + 1);
+    const KvPoolView pool = pool_view(&g_kv_manager, KVH, hd);
+
+    const int rows_x = T > B ? T : B;
+    __half* a16_x = (__half*)ws_get(WS_A16_X, a16_halves(rows_x, D) * sizeof(__half));
+    __half* a16_att = (__half*)ws_get(WS_A16_ATT, a16_halves(T, QD) * sizeof(__half));
+    __half* a16_h = (__half*)ws_get(WS_A16_H, a16_halves(T, F) * sizeof(__half));
+    const int ks_qkv = gemm_pick_ksplit(QD + 2 * KD, D, T);
+    const int ks_wo = gemm_pick_ksplit(D, QD, T);
+    const int ks_dn = gemm_pick_ksplit(D, F, T);
+    size_t slab_floats = (size_t)ks_qkv * Tpad * (QD + 2 * KD);
+    slab_floats = std::max(slab_floats, (size_t)ks_wo * Tpad * D);
+    slab_floats = std::max(slab_floats, (size_t)ks_dn * Tpad * D);
+    float* slab = (float*)ws_get(WS_SLAB, slab_floats * sizeof(float));
+    float* d_logits = (float*)ws_get(WS_LOGITS, (size_t)B * V * sizeof(float));
+    int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
+
+    launch_embed(s->x, m->embed, st.d_tokens, T, D);  // model.c:352-355
+
+    int pending = 0;  // split count of the residual-branch projection not yet added to x
+    for (int l = 0; l < p->n_layers; l++) {
+        const LayerPriv& lp = m->layers[l];
+        // x += previous w_down output; xb = rmsnorm(x) * rms_att          (model.c:393,361)
+        launch_rmsnorm_a16(a16_x, s->x, lp.rms_att, pending ? slab : nullptr, pending, Tpad, T, D, eps, nullptr, PC_RMSNORM);
+        // q,k,v = xb . [wq;wk;wv]^T                                        (model.c:363-365)
+        WeightEntry wqkv{lp.qkv, QD + 2 * KD, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
+        GemmEpilogue e_slab;
+        e_slab.kind = GemmEpilogue::SLAB;
+        e_slab.out = slab;
+        const int k1 = launch_gemm(wqkv, lp.qkv, QD + 2 * KD, a16_x, T, e_slab, ks_qkv, PC_GEMM_QKV);
+        // RoPE on q,k; K/V rows into the pool                              (model.c:368-377)
+        launch_rope_kv(s->q, nullptr, nullptr, slab, k1, Tpad, T, H, KVH, hd, st.d_pos, st.d_seq, st.d_tbl_off,
+                       st.d_tables, rope, pool, l, st.write_limit);
+        // attention over the block table -> fp16 hi/lo tiles               (model.c:380-383)
+        AttnArgs at{};
+        at.q = s->q;
+        at.out_a16 = a16_att;
+        at.pool = pool;
+        at.layer = l;
+        at.pos = st.d_pos;
+        at.seq = st.d_seq;
+        at.tbl_off = st.d_tbl_off;
+        at.tables = st.d_tables;
+        at.T = T; at.H = H; at.KVH = KVH; at.hd = hd;
+        at.max_pos = st.max_pos;
+        launch_paged_attention(at);
+        // wo projection; its slabs are folded into x by the next norm      (model.c:385-388)
+        WeightEntry wwo{lp.wo, D, QD, QD / 32, (long)(QD / 32) * TILE_HALVES, nullptr};
+        const int k2 = launch_gemm(wwo, lp.wo, D, a16_att, T, e_slab, ks_wo, PC_GEMM_WO);
+        launch_rmsnorm_a16(a16_x, s->x, lp.rms_ffn, slab, k2, Tpad, T, D, eps, nullptr, PC_RMSNORM);
+        // hb = silu(xb.w_gate^T) * (xb.w_up^T), fused in the epilogue      (model.c:389-391)
+        WeightEntry wgu{lp.gateup, 2 * F, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
+        GemmEpilogue e_sw;
+        e_sw.kind = GemmEpilogue::SWIGLU_A16;
+        e_sw.a16_out = a16_h;
+        launch_gemm(wgu, lp.gateup, 2 * F, a16_x, T, e_sw, 1, PC_GEMM_GATEUP);
+        // w_down projection; folded into x by the next layer's norm        (model.c:392-393)
+        WeightEntry wdn{lp.down, D, F, F / 32, (long)(F / 32) * TILE_HALVES, nullptr};
+        pending = launch_gemm(wdn, lp.down, D, a16_h, T, e_slab, ks_dn, PC_GEMM_DOWN);
+    }
+    // final norm only on the rows that produce logits, gathered            (model.c:396,411-414)
+    launch_rmsnorm_a16(a16_x, s->x, m->rms_final, pending ? slab : nullptr, pending, Tpad, B, D, eps, st.d_out_idx, PC_RMSNORM);
+    WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
+    GemmEpilogue e_f32;
+    e_f32.kind = GemmEpilogue::F32;
+    e_f32.out = d_logits;
+    e_f32.ldo = V;
+    launch_gemm(wh, m->head, V, a16_x, B, e_f32, 1, PC_GEMM_HEAD);   // model.c:418
+    launch_argmax(d_argmax, d_logits, B, V);
+
+    if (B > g_argmax_cap) {
+        if (g_argmax_host) HIP_CHECK(hipHostFree(g_argmax_host));
+        g_argmax_cap = B + 256;
+        HIP_CHECK(hipHostMalloc((void**)&g_argmax_host, (size_t)g_argmax_cap * sizeof(int), hipHostMallocDefault));
+    }
+    hipStream_t stream = rt().stream;
+    HIP_CHECK(hipMemcpyAsync(g_argmax_host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (rt().logits_mode == NVLLM_LOGITS_HOST)
+        HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // the call is synchronous, like the CPU reference
+    g_last_outputs = B;
+    g_last_logits_host = s->logits;
+    g_last_logits_dev = d_logits;
+    g_last_vocab = V;
+}
+
+const int* nvllm_last_argmax(int* num_outputs) {
+    if (num_outputs) *num_outputs = g_last_outputs;
+    return g_argmax_host;
+}
+
+// ------------------------------------------------------------------ sampler
+void build_sampler(Sampler* s, int vocab_size, float temperature, float topp, unsigned long long seed) {
+    s->state = seed;
+    s->temperature = temperature;
+    s->topp = topp;
+    s->vocab_size = vocab_size;
+    s->probindex = (ProbIndex*)malloc((size_t)vocab_size * sizeof(ProbIndex));
+    srand((unsigned int)seed);  // reference sampler.c:26
+}
+
+int sample(Sampler* s, float* logits) {
+    ensure_init();
+    if (s->temperature != 0.0f)
+        NVLLM_FATAL("sample(): temperature > 0 is not available on the GPU path yet; link the reference's "
+                    "sampler.c (it works on the host-visible logits) or use temperature 0");
+    const int V = s->vocab_size;
+    // a row of the most recent forward pass: answered from the arg-max the GPU already computed
+    if (g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
+        const size_t d = (size_t)(logits - g_last_logits_host);
+        if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) return g_argmax_host[d / (size_t)V];
+    }
+    // any other host row: upload and reduce with the same kernel
+    float* dev = (float*)ws_get(WS_MISC, (size_t)V * sizeof(float) + 256);
+    int* dres = (int*)ws_get(WS_MISC2, 256);
+    HIP_CHECK(hipMemcpyAsync(dev, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice, rt().stream));
+    launch_argmax(dres, dev, 1, V);
+    int res = 0;
+    HIP_CHECK(hipMemcpyAsync(&res, dres, sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    return res;
+}
+
+}  // extern "C"

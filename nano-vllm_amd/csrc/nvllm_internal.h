@@ -1,0 +1,207 @@
+// nvllm_internal.h -- declarations shared by the translation units of
+// libnvllm_hip.so.  Nothing here is part of the public ABI (see include/*.h).
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+extern "C" {
+#include "backend.h"
+#include "model.h"
+#include "nvllm.h"
+#include "ops.h"
+#include "sampler.h"
+#include "structs.h"
+}
+
+#define HIP_CHECK(expr)                                                                       \
+    do {                                                                                      \
+        hipError_t err__ = (expr);                                                            \
+        if (err__ != hipSuccess) {                                                            \
+            fprintf(stderr, "nvllm: HIP error %d (%s) at %s:%d: %s\n", (int)err__,            \
+                    hipGetErrorString(err__), __FILE__, __LINE__, #expr);                     \
+            abort();                                                                          \
+        }                                                                                     \
+    } while (0)
+
+#define NVLLM_FATAL(...)                                   \
+    do {                                                   \
+        fprintf(stderr, "nvllm: " __VA_ARGS__);            \
+        fprintf(stderr, " (%s:%d)\n", __FILE__, __LINE__); \
+        abort();                                           \
+    } while (0)
+
+namespace nvllm {
+
+// ------------------------------------------------------------------ layouts
+// "Tile order" (used for fp16 weight matrices and for fp16 activations): a
+// [rows, K] matrix is cut into tiles of 16 rows x 32 k.  One tile is 512 halves
+// (1 KiB) stored in the register order of one v_mfma_f32_16x16x32_f16 operand:
+//   element (r, k) of the tile sits at half index  lane*8 + (k & 7),
+//   lane = (r & 15) + 16 * ((k >> 3) & 3),
+// so lane l of a wave reads its whole operand fragment with one 16-byte load and a
+// wave reads the tile as 1 KiB of consecutive bytes.  Tiles of one 16-row block
+// are consecutive in k:  tile(rb, kb) = rb * Kb + kb,  Kb = ceil(K / 32).
+//
+// Activations additionally carry two planes per tile, "hi" then "lo":
+//   x = float(hi) + float(lo) + O(2^-22 |x|),  hi = fp16(x), lo = fp16(x - hi),
+// so that two fp16 MFMAs reproduce an fp32 x fp16 product to fp32 accuracy.
+//   a16 tile(tb, kb, plane) = ((tb * Kb + kb) * 2 + plane) * 512 halves.
+constexpr int TILE_HALVES = 512;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t a16_halves(int tokens, int K) {
+    return (size_t)cdiv(tokens, 16) * cdiv(K, 32) * 2 * TILE_HALVES;
+}
+
+// A weight matrix registered by load_model.  `handle` is what the public structs
+// carry; matmul() looks it up.
+struct WeightEntry {
+    const __half* tiles;  // first tile of n-block 0
+    int N, K;             // logical shape [N, K]
+    int Kb;               // k-tiles per n-block
+    long nb_stride;       // halves between consecutive n-blocks of THIS matrix
+    const __half* rowmajor; // non-null for the embedding table ([N, K] fp16 row-major)
+};
+const WeightEntry* find_weight(const void* handle);
+void register_weight(const void* handle, const WeightEntry& e);
+void unregister_weight(const void* handle);
+
+// ------------------------------------------------------------------ runtime
+struct Runtime {
+    bool inited = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int logits_mode = NVLLM_LOGITS_HOST;
+    int kv_elem_bytes = 4;
+    int graph_mode = 0;
+    int num_cus = 256;
+};
+Runtime& rt();
+void ensure_init();
+
+// Grow-only device scratch, one buffer per slot.
+enum WsSlot {
+    WS_A16_X = 0,   // normalised activations feeding qkv / gate-up / classifier
+    WS_A16_ATT,     // attention output feeding wo
+    WS_A16_H,       // swiglu output feeding w_down
+    WS_SLAB,        // split-K partial sums
+    WS_ATT_PART,    // attention split partials (acc, m, l)
+    WS_LOGITS,      // device logits [B, V]
+    WS_ARGMAX,      // device argmax [B]
+    WS_STEP,        // per-call integer arrays (tokens, pos, seq ids, tables ...)
+    WS_MISC,
+    WS_MISC2,
+    WS_COUNT
+};
+void* ws_get(WsSlot slot, size_t bytes);
+
+// Pinned host staging for the integer arrays of one call.  stage_ints() copies
+// `n` ints into a fresh region of a pinned ring and enqueues the H2D copy into
+// `dst`; the source may be reused when it returns.
+void stage_ints(int* dst_device, const int* src_host, size_t n);
+int* pinned_ints(size_t n);   // ring allocation, for callers that fill it themselves
+
+// RoPE angle table for (theta, head_dim), covering positions [0, min_positions):
+// float2 {cos, sin} per (position, pair), computed on the host with the same libm
+// calls as the reference (src/kernels/layers.c:119-122) and cached in HBM.
+const float2* rope_table(float theta, int head_dim, int min_positions);
+
+// ---------------------------------------------------------------- profiling
+enum ProfClass {
+    PC_EMBED = 0,
+    PC_RMSNORM,
+    PC_GEMM_QKV,
+    PC_GEMM_WO,
+    PC_GEMM_GATEUP,
+    PC_GEMM_DOWN,
+    PC_GEMM_HEAD,
+    PC_GEMM_OTHER,
+    PC_ROPE_KV,
+    PC_ATTN,
+    PC_ATTN_COMBINE,
+    PC_ELEMWISE,
+    PC_ARGMAX,
+    PC_PACK,
+    PC_COUNT
+};
+struct ProfScope {  // brackets launches on rt().stream with an event pair when timing is on
+    ProfScope(int cls, double bytes, double flops);
+    ~ProfScope();
+    int slot;
+};
+
+// ----------------------------------------------------- kernel launchers (device ptrs)
+struct GemmEpilogue {
+    enum Kind { F32 = 0, SLAB = 1, SWIGLU_A16 = 2 } kind = F32;
+    float* out = nullptr;      // F32: [T, ldo]; SLAB: [ksplit][Tpad][N]
+    int ldo = 0;
+    __half* a16_out = nullptr; // SWIGLU_A16: tiles of [T, N/2]
+};
+// out = A16[T, K] x W[N, K]^T.  Returns the k-split it used (1 unless SLAB).
+int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
+                const GemmEpilogue& epi, int force_ksplit, int prof_cls);
+int gemm_pick_ksplit(int N, int K, int T);
+
+void launch_pack_a16(__half* a16, const float* in, int T, int K);
+void launch_slab_reduce(float* out, const float* slabs, int ksplit, int T, int Tpad, int N,
+                        const float* residual /*nullable, may alias out*/);
+void launch_matmul_f32w(float* out, const float* in, const float* w, int T, int K, int N);
+
+// x[t,:] (+= sum of slabs) ; a16 = rmsnorm(x) * g.  slabs may be null.  When
+// `gather` is non-null, row r of the output comes from x[gather[r]] and x is not
+// written.
+void launch_rmsnorm_a16(__half* a16, float* x, const float* gain, const float* slabs, int ksplit,
+                        int Tpad, int T, int D, float eps, const int* gather, int prof_cls);
+void launch_rmsnorm_f32(float* o, const float* x, const float* gain, int D, int T, float eps);
+
+struct KvPoolView {
+    void* k;
+    void* v;
+    int elem_bytes;    // 4 or 2
+    int block_size;
+    int num_blocks;
+    long layer_stride; // elements
+};
+// q,k,v <- sum of slabs (if any), rotate q,k, write q (fp32) and scatter k,v rows.
+void launch_rope_kv(float* q, float* k, float* v, const float* slabs, int ksplit, int Tpad, int T,
+                    int H, int KVH, int hd, const int* pos, const int* seq, const int* tbl_off,
+                    const int* tables, const float2* rope, const KvPoolView& pool, int layer,
+                    int write_limit);
+void launch_rope(float* q, float* k, const int* pos, int pos0, const float2* rope, int T, int H,
+                 int KVH, int hd);
+void launch_kv_write(const float* k, const float* v, const int* pos, int pos0, const int* seq,
+                     const int* tbl_off, const int* tables, const KvPoolView& pool, int layer, int T,
+                     int KVH, int hd);
+
+struct AttnArgs {
+    const float* q;        // [T, H*hd]
+    float* out_f32;        // [T, H*hd] or null
+    __half* out_a16;       // tiles of [T, H*hd] or null
+    KvPoolView pool;
+    int layer;
+    const int* pos;        // device [T] (null: pos0 + t)
+    int pos0;
+    const int* seq;        // device [T] (null: single table at tbl_off 0)
+    const int* tbl_off;    // device [n_seqs]
+    const int* tables;     // device, concatenated block tables (null: contiguous cache)
+    int T, H, KVH, hd;
+    int max_pos;           // largest position in the batch (host knowledge, for split sizing)
+};
+void launch_paged_attention(const AttnArgs& a);
+
+void launch_embed(float* x, const __half* table, const int* tokens, int T, int D);
+void launch_swiglu(float* out, const float* g, const float* u, long n);
+void launch_accum(float* a, const float* b, long n);
+void launch_softmax(float* x, int n);
+void launch_argmax(int* out, const float* logits, int B, int V);
+void launch_tile_weights(__half* tiles, const __half* rowmajor, int N, int K, long nb_stride);
+void launch_f32_to_f16(__half* dst, const float* src, size_t n);
+void launch_f16_to_f32(float* dst, const __half* src, size_t n);
+
+}  // namespace nvllm

@@ -1,0 +1,30 @@
+// step_arrays.h -- device copies of the host-side description of one ragged batch.
+#pragma once
+#include "nvllm_internal.h"
+
+namespace nvllm {
+
+struct StepArrays {
+    int T, B;
+    int n_seqs;
+    int max_pos;      // largest position in the batch
+    int write_limit;  // tokens [0, write_limit) get their K/V stored (see attention.c:159-162)
+    int* d_tokens;    // [T]        (null when not supplied)
+    int* d_pos;       // [T]
+    int* d_seq;       // [T]
+    int* d_out_idx;   // [B]
+    int* d_tbl_off;   // [n_seqs]   start of each sequence's table inside d_tables
+    int* d_tables;    // concatenated logical->physical block maps
+};
+
+// Copies the arrays into the pinned ring, lays the block tables of the sequences
+// that occur in the batch end to end, and enqueues ONE host-to-HBM copy.
+// `tables` (indexed by seq id) or `single` (one table, positions pos0 + t) may be
+// null for operators that do not touch the pool.
+StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids, int T,
+                      const int* output_indices, int B, BlockTable** tables, const BlockTable* single,
+                      int pos0, int block_size);
+
+KvPoolView pool_view(const KVCacheManager* mgr, int n_kv_heads, int head_dim);
+
+}  // namespace nvllm

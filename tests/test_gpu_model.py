@@ -1,0 +1,65 @@
+"""GPU parity of the forward pass (transformer_batch behind the N-sequence driver)
+against the CPU oracle on the same model file and requests."""
+import numpy as np
+import pytest
+
+from nvllm_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+LOGITS_TOL = 2e-2   # the bar stated for this path: max-abs, fp16 weights, fp32 accumulation
+TIGHT_TOL = 2e-4    # what this implementation is expected to achieve
+
+
+def _compare_runs(g, o, check_logits=True):
+    np.testing.assert_array_equal(g["trace"], o["trace"])            # allocator: bit-exact
+    for a, b in zip(g["tables"], o["tables"]):
+        np.testing.assert_array_equal(a, b)
+    assert len(g["steps"]) == len(o["steps"])
+    worst = 0.0
+    for sg, so in zip(g["steps"], o["steps"]):
+        for key in ("tokens", "pos", "seq_ids", "output_indices"):
+            np.testing.assert_array_equal(sg[key], so[key])          # same ragged batches
+        if check_logits:
+            worst = max(worst, float(np.abs(sg["logits"] - so["logits"]).max()))
+        np.testing.assert_array_equal(sg["sampled"], so["sampled"])  # greedy tokens identical
+    for a, b in zip(g["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+    return worst
+
+
+@pytest.mark.parametrize("name,chunk", [("tiny", 16), ("tiny", 7), ("tiny-mha48", 1000)])
+def test_mixed_prefill_decode_tiny(hip, oracle, tmp_models, name, chunk):
+    path, shape = tmp_models(name)
+    prompts = synth.make_requests(4, 3, 50, shape.vocab_size, seed=5)
+    kw = dict(n_new=24, arrivals=[0, 2, 2, 9], collect_logits=True, chunk_size=chunk, temperature=0.0)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    g = util.run_engine(hip, path, prompts, **kw)
+    worst = _compare_runs(g, o)
+    assert worst < TIGHT_TOL < LOGITS_TOL, worst
+
+
+def test_stories15m_shape_greedy_256(hip, oracle, tmp_models):
+    """head_dim 48, MHA, vocab 32000: 3 sequences, 256 greedy steps each."""
+    path, shape = tmp_models("stories15M", max_seq_len=512)
+    prompts = synth.make_requests(3, 20, 90, shape.vocab_size, seed=9)
+    kw = dict(n_new=256, arrivals=[0, 0, 3], collect_logits=True, chunk_size=64, temperature=0.0, max_steps=2000)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    g = util.run_engine(hip, path, prompts, **kw)
+    worst = _compare_runs(g, o)
+    assert worst < TIGHT_TOL, worst
+
+
+def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
+    path, shape = tmp_models("tiny")
+    prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=6)
+    kw = dict(n_new=16, chunk_size=8, temperature=0.0)
+    a = util.run_engine(hip, path, prompts, **kw)
+    hip.nvllm_set_logits_mode(1)
+    try:
+        b = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_logits_mode(0)
+    for x, y in zip(a["histories"], b["histories"]):
+        np.testing.assert_array_equal(x, y)
