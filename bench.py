@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Decode-throughput benchmark of the forward pass on MI355X.
+
+One "step" = one pass of the hot path (transformer_batch + greedy arg-max) over one
+ragged batch in which every sequence decodes one token.  Workload at N = 1:
+TinyLlama-1.1B shape (random-init fp16 model file in the reference's format), 64
+concurrent requests, 1024-token prompts prefilled in 512-token chunks, greedy
+decoding (BASELINE.json configs[2]).  With --gpus N the request streams shard as N
+data-parallel replicas, one process per GPU, each with its own weights copy and
+block pool; there is no data-path collective, so scaling is "weak".
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` is decode tokens/s over all ranks with the
+batch already resident in HBM (the only host traffic inside a step is the 64-entry
+integer batch description going up and 64 token ids coming back).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+
+# --------------------------------------------------------------------------- helpers
+def shard_requests(n_requests_per_gpu: int, rank: int, world: int):
+    """Data-parallel placement: request r of the node-wide stream goes to replica
+    r mod world.  Every replica gets the same number of requests (weak scaling)."""
+    total = n_requests_per_gpu * world
+    return [r for r in range(total) if r % world == rank]
+
+
+def algorithmic_bytes_per_decode_step(shape, batch, ctx_lens, kv_bytes):
+    """Bytes one decode step must move at least once: every weight once, K/V of
+    every cached position once per kv head, the new K/V rows, the token ids."""
+    D, F, L, V = shape.dim, shape.hidden_dim, shape.n_layers, shape.vocab_size
+    QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
+    weights = 2 * (L * (2 * D * QD + 2 * D * KD + 3 * D * F) + V * D) + 4 * (2 * L + 1) * D
+    kv_row = L * 2 * KD * kv_bytes
+    kv_read = sum(c + 1 for c in ctx_lens) * kv_row
+    kv_write = batch * kv_row
+    return weights + kv_read + kv_write + batch * (D * 2 + 8)
+
+
+class DistEnv:
+    """torch.distributed plumbing: barrier and max/sum over ranks.  Degenerates to
+    no-ops for a single process."""
+
+    def __init__(self, want_gpus: int, backend: str | None = None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.torch = None
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            self.backend = backend
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            self.device = torch.device("cuda", self.local_rank) if backend == "nccl" else torch.device("cpu")
+        if want_gpus != self.world and self.rank == 0:
+            print(f"bench: --gpus {want_gpus} but WORLD_SIZE is {self.world}; using {self.world}", file=sys.stderr)
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def reduce(self, value: float, op: str) -> float:
+        if not self.dist:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def timed_steps(env: DistEnv, sync, step, warmup: int, steps: int):
+    """W untimed steps, then exactly K steps between barrier+sync brackets; returns
+    the MAX elapsed seconds over ranks."""
+    for _ in range(warmup):
+        step()
+    sync()
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    env.barrier()
+    return env.reduce(elapsed, "MAX")
+
+
+# ------------------------------------------------------------------------ the bench
+def ensure_model(path, shape, seed, env):
+    from nvllm_amd import synth
+    want = 28 + 2 * shape.n_params(shared=False)
+    if env.rank == 0 and not (os.path.exists(path) and os.path.getsize(path) == want):
+        t0 = time.time()
+        synth.write_model(path, shape, seed=seed)
+        print(f"bench: wrote {path} ({want / 1e9:.2f} GB) in {time.time() - t0:.1f}s", file=sys.stderr)
+    env.barrier()
+
+
+def run_gpu(args, env, shape, model_path):
+    from nvllm_amd import capi, synth
+    lib = capi.load_hip()           # raises if the HIP library is not built: no fall-back
+    lib.nvllm_set_device(env.local_rank)
+    lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
+    lib.nvllm_set_logits_mode(1)    # only token ids return to the host
+    if args.graph:
+        lib.nvllm_set_graph_mode(1)
+    B = args.batch
+    # sequences that finish their prefill early already decode while the others are
+    # still prefilling (continuous batching), so budget those steps too
+    chunks_per_seq = -(-args.prompt_len // args.chunk)
+    per_step = max(1, args.max_seq_len // min(args.chunk, args.prompt_len))
+    prefill_steps = -(-B * chunks_per_seq // per_step) + 2
+    n_new = prefill_steps + args.warmup + args.steps + args.profile_steps + 8
+    if args.prompt_len + n_new > args.max_seq_len:
+        raise SystemExit(f"prompt {args.prompt_len} + {n_new} new tokens exceeds max_seq_len {args.max_seq_len}")
+    ids = shard_requests(B, env.rank, env.world)
+    prompts = synth.make_requests(B * env.world, args.prompt_len, args.prompt_len, shape.vocab_size, seed=11)
+    eng = capi.Engine(lib, model_path, B, chunk_size=args.chunk, temperature=0.0,
+                      max_seq_len=args.max_seq_len, max_steps=1 << 30)
+    for slot, r in enumerate(ids):
+        eng.set_request(slot, prompts[r], n_new, 0)
+
+    # ---- prefill (chunked), reported alongside
+    lib.device_sync()
+    t0 = time.perf_counter()
+    while True:
+        states = [eng.seq_state(i) for i in range(B)]
+        if all(s["pos"] >= s["n_prompt"] for s in states):
+            break
+        eng.step()
+    lib.device_sync()
+    prefill_s = time.perf_counter() - t0
+    st = eng.stats()
+    prefill_tokens = st.tokens_forwarded
+    ctx0 = [eng.seq_state(i)["pos"] for i in range(B)]
+
+    # ---- timed decode
+    eng.reset_stats()
+    elapsed = timed_steps(env, lib.device_sync, eng.step, args.warmup, args.steps)
+    st = eng.stats()
+    assert st.decode_step_tokens == (args.warmup + args.steps) * B, "a timed step was not a pure decode step"
+    ctx_mid = [c + args.warmup + args.steps // 2 for c in ctx0]
+    step_bytes = algorithmic_bytes_per_decode_step(shape, B, ctx_mid, args.kv_bytes)
+
+    # ---- per-kernel durations from HIP events on the library stream (same workload,
+    #      the steps right after the timed region; events would perturb the timing)
+    prof = {}
+    if env.rank == 0 and args.profile_steps > 0:
+        lib.nvllm_prof_reset()
+        lib.nvllm_prof_enable(1)
+        for _ in range(args.profile_steps):
+            eng.step()
+        lib.nvllm_prof_enable(0)
+        for c in range(lib.nvllm_prof_num_classes()):
+            n, ms, by, fl = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+            lib.nvllm_prof_get(c, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
+            if n.value:
+                prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, total_ms=ms.value,
+                                                             bytes=by.value, flops=fl.value)
+    hist = eng.history(0)[-4:].tolist()
+    eng.close()
+    return dict(elapsed=elapsed, prefill_s=prefill_s, prefill_tokens=prefill_tokens, step_bytes=step_bytes,
+                prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist)
+
+
+def cpu_baseline(args, shape, model_path):
+    """The reference CPU path (oracle/_ref, the reference's own kernels compiled here)
+    or, where that build is absent, this repository's restatement of it, timed on a
+    bounded sample: the same batch of sequences with 2-token prompts, one prefill
+    step and `cpu_steps` decode steps."""
+    from nvllm_amd import capi, synth
+    kind = "reference" if os.path.exists(capi.REF_LIB) else "port"
+    lib = capi.load_ref() if kind == "reference" else capi.load_oracle()
+    B = args.batch
+    prompts = synth.make_requests(B, 2, 2, shape.vocab_size, seed=11)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)                     # the reference's loader prints a page of text
+    try:
+        eng = capi.Engine(lib, model_path, B, chunk_size=args.chunk, temperature=0.0,
+                          max_seq_len=256, max_steps=1 << 30)
+        for i, p in enumerate(prompts):
+            eng.set_request(i, p, args.cpu_steps + 1, 0)
+        eng.step()                          # prefill step (2 tokens per sequence)
+        eng.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            eng.step()
+        dt = time.perf_counter() - t0
+        eng.close()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    return dict(value=round(B * args.cpu_steps / dt, 3), unit="tokens/s", cores=cores, kind=kind,
+                sample=f"{args.cpu_steps} decode steps of {B} sequences at context 2-{2 + args.cpu_steps} "
+                       f"({B * args.cpu_steps} tokens, {dt:.1f} s wall, OpenMP)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="tinyllama-1.1b")
+    ap.add_argument("--batch", type=int, default=64, help="concurrent sequences per GPU")
+    ap.add_argument("--prompt-len", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--max-seq-len", type=int, default=2048)
+    ap.add_argument("--kv-bytes", type=int, default=4, choices=(2, 4))
+    ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="0 disables the CPU baseline leg")
+    ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
+    args = ap.parse_args()
+
+    from nvllm_amd import synth
+    env = DistEnv(args.gpus)
+    shape = synth.ModelShape.named(args.model, max_seq_len=args.max_seq_len)
+    model_path = os.path.join(args.model_dir, f"nvllm_{args.model}_s{args.max_seq_len}_seed0.bin")
+    ensure_model(model_path, shape, 0, env)
+
+    r = run_gpu(args, env, shape, model_path)
+    N, K, B = env.world, args.steps, args.batch
+    ms_per_step = r["elapsed"] / K * 1e3
+    value = B * N * K / r["elapsed"]
+    prefill_tps = env.reduce(r["prefill_tokens"] / r["prefill_s"], "SUM")
+
+    if env.rank == 0:
+        roofline = None
+        if r["prof"]:
+            name, d = max(r["prof"].items(), key=lambda kv: kv[1]["total_ms"])
+            avg_ms = d["total_ms"] / d["launches"]
+            achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_kernel_us=round(avg_ms * 1e3, 2), launches=d["launches"],
+                            algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
+        cpu = None
+        if N == 1 and args.cpu_steps > 0:
+            cpu = cpu_baseline(args, shape, model_path)
+        step_gbs = r["step_bytes"] / (ms_per_step * 1e-3) / 1e9
+        line = {
+            "metric": "decode tokens/sec (node) + % HBM peak, TinyLlama-1.1B paged batch 64",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (fp16 weights as hi/lo-split fp16 MFMA, f32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} shape, random-init fp16 model.bin, {B} concurrent requests per GPU, "
+                                   f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
+                                   f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
+                                   f"mean context {r['ctx']} in the timed region",
+                       "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes,
+                       "graph_replay": bool(args.graph)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "step_hbm": {"algorithmic_bytes_per_step": int(r["step_bytes"]), "achieved_GBps": round(step_gbs, 1),
+                         "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+            "prefill_tokens_per_s": round(prefill_tps, 1),
+            "kernels": {k: {"launches": v["launches"], "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2),
+                            "GBps": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in r["prof"].items()},
+        }
+        print(json.dumps(line), flush=True)
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,231 +1,286 @@
 // attention.hip -- causal attention of a ragged batch over the block pool
 // (reference src/kernels/attention.c:256-336 and its single-sequence / contiguous
-// siblings), fp32 arithmetic throughout.
+// siblings) in exact fp32 on the matrix cores.
 //
-// One WAVE owns one work item = (token, group of GT query heads that share a KV
-// head, slice of the key range).  It walks its keys 64 at a time:
-//   1. the 64 key rows of the KV head (one page = 16 rows) are staged into the
-//      wave's private LDS tile with 16-byte loads, rows padded by 16 bytes so that
-//      the per-key reads of step 2 are bank-conflict free;
-//   2. lane = key: each lane forms q.k over the head dimension for all GT heads
-//      (q comes in through scalar loads), scales after the dot like the reference;
-//   3. online softmax per head with wave-wide max / sum reductions;
-//   4. the value rows replace the keys in the same LDS tile; lane = output
-//      dimension accumulates sum_j p_j v_j, p_j broadcast with v_readlane.
-// Items of one token that cover different key slices leave (acc, max, sum)
-// partials which k_attn_combine merges.  Output is either fp32 rows or the
-// fp16 hi/lo tile order the output projection consumes.
+// K and V are streamed from HBM exactly once per (sequence, kv head) and go
+// straight from global memory into v_mfma_f32_16x16x4_f32 operands -- no LDS, no
+// cross-lane broadcast.  One WAVE owns one work item:
+//     (run of up to CT consecutive tokens of one sequence) x (group of GT query
+//     heads sharing a KV head) x (slice of the key pages),   CT * GT = 16.
+// The 16 (token, head) pairs are the 16 "columns" of every MFMA; a decode token
+// fills GT of them, a prefill chunk all 16, so prefill re-reads K/V CT times less.
+//
+// Per page (16 keys, the pool's block size -- one page is 16 consecutive rows):
+//   S^T[key, col] = sum_d K[key, d] * Q[col, d]      A = K (lane: key = l&15, 4 dims
+//                                                     chosen by l>>4), B = Q^T
+//       -> lane (col = l&15, g = l>>4) holds the scores of keys 4g..4g+3 of ITS column,
+//          so max / sum / rescale are lane-local plus two 16-lane-stride shuffles;
+//   O^T[d, col]  += sum_key V[key, d] * P[col, key]   A = V^T, B = P^T: the score
+//          registers are already in B-operand order (k = key 4g+s  <->  register s),
+//          and the result keeps `col` on the lane, next to its running max and sum.
+// fp32 MFMA is an exact fma chain, so the arithmetic is fp32 throughout like the
+// reference; only the summation order differs.  Key slices of one column leave
+// (acc, max, sum) partials that k_attn_combine merges.
 #include "nvllm_internal.h"
 
 namespace nvllm {
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
 
 struct AttnKArgs {
     const float* q;
     const void* pool_k;
     const void* pool_v;
-    long layer_off;  // elements
-    int bs;
+    long layer_off;   // elements
+    long rowstride;   // elements between consecutive positions of a page (KVH * hd)
+    int page;         // positions per page as seen by the kernel (16)
     const int* pos;
     int pos0;
     const int* seq;
     const int* tbl_off;
     const int* tables;
-    int T, H, KVH;
+    const int2* runs; // (first token, token count) per item
+    int n_runs;
+    int H, KVH, GT, CT;
+    int NG, group, gt_shift;
     int nsplit;
     float scale;
     float* out_f32;
     __half* out_a16;
     int Kb_out;
-    float* part_acc;  // [item][GT][HD]
-    float* part_ml;   // [item][GT][2]
+    float* part_acc;  // [t][h][split][HD]
+    float* part_ml;   // [t][h][split][2]
 };
-
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float lane_bcast(float v, int j) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-}
-
-__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 load4(const __half* p) {
-    const uint2 raw = *reinterpret_cast<const uint2*>(p);
-    const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
-    const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
-    const float2 fa = __half22float2(a), fb = __half22float2(b);
-    return make_float4(fa.x, fa.y, fb.x, fb.y);
-}
 
 struct alignas(16) H8 {
     __half v[8];
 };
 
-template <int HD, int GT, int WAVES, typename KVT>
-__global__ __launch_bounds__(WAVES * 64) void k_paged_attn(AttnKArgs a) {
-    constexpr int CPR = HD / 4;     // 16-byte chunks per row
-    constexpr int STRIDE = HD + 4;  // floats; odd number of chunks => conflict-free row reads
-    constexpr int DPL = (HD + 63) / 64;
-    __shared__ float smem[WAVES][64 * STRIDE];
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+    const uint2 raw = *reinterpret_cast<const uint2*>(p);
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&raw.x));
+    const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&raw.y));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
 
+template <int HD, typename KVT>
+struct PageRegs {
+    static constexpr int NC = HD / 16;        // 16-dim chunks of a key row
+    static constexpr int NV = (HD + 63) / 64;  // 64-dim groups of a value row
+    float4 k[NC];
+    float4 v[NV][4];
+};
+
+// One page of operands.  `live` = number of rows of the page that hold positions
+// <= the item's last position.  Row indices are clamped to live-1 instead of being
+// predicated: a clamped row is a written (finite) row, its score is replaced by
+// -inf and its probability is exactly 0, so it contributes 0 * finite = 0.  All
+// loads are unconditional, which lets the compiler wait with counted vmcnt and
+// keep the next page in flight while this one is consumed.
+template <int HD, typename KVT>
+__device__ __forceinline__ void load_page(PageRegs<HD, KVT>& r, const KVT* __restrict__ kpage,
+                                          const KVT* __restrict__ vpage, int live, int rowstride, int lane) {
+    constexpr int NC = HD / 16, NV = (HD + 63) / 64;
+    const int x = lane & 15, g = lane >> 4;
+    // K as the A operand: lane (key = x, dims 16c + 4g .. +3)
+    const int koff = min(x, live - 1) * rowstride + 4 * g;
+#pragma unroll
+    for (int c = 0; c < NC; c++) r.k[c] = ld4(kpage + koff + 16 * c);
+    // V^T as the A operand: lane (dims 4x .. 4x+3 [+64n], key 4g + s)
+    const int dx = 4 * x < HD ? 4 * x : 0;   // lanes past the head width re-read dims 0..3 (result rows unused)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int voff = min(4 * g + s, live - 1) * rowstride + dx;
+#pragma unroll
+        for (int n = 0; n < NV; n++) r.v[n][s] = ld4(vpage + voff + (64 * n + 4 * x < HD ? 64 * n : 0));
+    }
+}
+
+template <int HD, typename KVT>
+__global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
+    constexpr int NC = HD / 16, NV = (HD + 63) / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NG = a.H / GT;
-    const long item = (long)blockIdx.x * WAVES + wave;
-    if (item >= (long)a.T * NG * a.nsplit) return;
-    const int split = (int)(item % a.nsplit);
-    const int hg = (int)((item / a.nsplit) % NG);
-    const int t = (int)(item / ((long)a.nsplit * NG));
-    const int h0 = hg * GT;
-    const int kvh = h0 / (a.H / a.KVH);
-    const int p = a.pos ? a.pos[t] : a.pos0 + t;
-    const int nkeys = p + 1;
-    const int per = ((nkeys + 63) / 64 + a.nsplit - 1) / a.nsplit * 64;  // keys per slice, whole tiles
-    const int kbegin = split * per;
-    const int kend = min(nkeys, kbegin + per);
-    const int* table = a.tables ? a.tables + (a.seq ? a.tbl_off[a.seq[t]] : 0) : nullptr;
+    // 32-bit index arithmetic throughout (64-bit division is a long software loop)
+    const unsigned NG = (unsigned)a.NG;
+    const unsigned widx = blockIdx.x * 4u + (unsigned)wave;
+    if (widx >= (unsigned)a.n_runs * NG * (unsigned)a.nsplit) return;
+    // head group fastest: the waves of a workgroup read neighbouring 256-byte
+    // pieces of the same K/V rows at the same time (DRAM page locality)
+    const int hg = (int)(widx % NG);
+    const unsigned rest = widx / NG;
+    const int split = (int)(rest % (unsigned)a.nsplit);
+    const int2 run = a.runs[rest / (unsigned)a.nsplit];
+    const int t0 = run.x, ntok = run.y;
+    const int h0 = hg * a.GT;
+    const int kvh = (int)((unsigned)h0 / (unsigned)a.group);
+
+    // this lane's column
+    const int x = lane & 15, g = lane >> 4;
+    const int ctok = x >> a.gt_shift, chead = x & (a.GT - 1);   // GT is a power of two
+    const bool cvalid = ctok < ntok;
+    const int tcol = t0 + (cvalid ? ctok : 0);
+    const int pcol = a.pos ? a.pos[tcol] : a.pos0 + tcol;
+    const int plim = cvalid ? pcol : -1;   // last key this column may see (none for padding columns)
+    const int tlast = t0 + ntok - 1;
+    const int plast = a.pos ? a.pos[tlast] : a.pos0 + tlast;   // positions rise within a run
+    const int npages = (plast >> 4) + 1;   // 16 == 16
+    const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
+    const int pg_begin = split * per;
+    const int pg_end = min(npages, pg_begin + per);
+    const int* table = a.tables ? a.tables + (a.seq ? a.tbl_off[a.seq[t0]] : 0) : nullptr;
     const KVT* pk = reinterpret_cast<const KVT*>(a.pool_k) + a.layer_off + (size_t)kvh * HD;
     const KVT* pv = reinterpret_cast<const KVT*>(a.pool_v) + a.layer_off + (size_t)kvh * HD;
-    const long rowstride = (long)a.KVH * HD;
-    float* tile = smem[wave];
-    const float* __restrict__ qrow = a.q + ((size_t)t * a.H + h0) * HD;
 
-    float m[GT], l[GT], acc[GT][DPL];
+    // Q^T as the B operand: lane (col = x, dims 16c + 4g .. +3)
+    float4 qv[NC];
+    {
+        const float* qr = a.q + ((size_t)tcol * a.H + h0 + chead) * HD + 4 * g;
 #pragma unroll
-    for (int g = 0; g < GT; g++) {
-        m[g] = -INFINITY;
-        l[g] = 0.f;
-#pragma unroll
-        for (int e = 0; e < DPL; e++) acc[g][e] = 0.f;
+        for (int c = 0; c < NC; c++) qv[c] = cvalid ? ld4(qr + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    for (int k0 = kbegin; k0 < kend; k0 += 64) {
-        // ---- 1. stage 64 key rows
+    float m = -INFINITY, lsum = 0.f;
+    f4_t oacc[NV][4];
 #pragma unroll
-        for (int i = 0; i < CPR; i++) {
-            const int idx = i * 64 + lane;
-            const int key = idx / CPR, c = idx % CPR;
-            const int ta = k0 + key;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ta < kend) {
-                const long row = table ? (long)table[ta / a.bs] * a.bs + (ta % a.bs) : (long)ta;
-                v = load4(pk + row * rowstride + c * 4);
-            }
-            *reinterpret_cast<float4*>(tile + key * STRIDE + c * 4) = v;
+    for (int n = 0; n < NV; n++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) oacc[n][e] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int rs = (int)a.rowstride;
+    // page -> operand base pointers (wave-uniform: scalar loads of the block table)
+    auto kbase = [&](int pg) -> const KVT* {
+        const int q = min(pg, pg_end - 1);
+        const long row = table ? (long)table[q] * 16 : (long)q * 16;
+        return pk + row * rs;
+    };
+    auto vbase = [&](int pg) -> const KVT* {
+        const int q = min(pg, pg_end - 1);
+        const long row = table ? (long)table[q] * 16 : (long)q * 16;
+        return pv + row * rs;
+    };
+    auto live_of = [&](int pg) -> int { return min(16, plast - min(pg, pg_end - 1) * 16 + 1); };
+
+    auto compute = [&](const PageRegs<HD, KVT>& r, int pg) {
+        // ---- scores: two accumulators so consecutive MFMAs are independent
+        f4_t s0 = f4_t{0.f, 0.f, 0.f, 0.f}, s1 = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r.k[c].x, qv[c].x, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r.k[c].y, qv[c].y, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r.k[c].z, qv[c].z, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r.k[c].w, qv[c].w, s1, 0, 0, 0);
         }
-        // ---- 2. scores, lane = key
-        float s[GT];
+        float sc[4];
+        float mx = -INFINITY;
+        const int kfirst = pg * 16 + 4 * g;
 #pragma unroll
-        for (int g = 0; g < GT; g++) s[g] = 0.f;
-#pragma unroll
-        for (int c = 0; c < CPR; c++) {
-            const float4 kv = *reinterpret_cast<const float4*>(tile + lane * STRIDE + c * 4);
-#pragma unroll
-            for (int g = 0; g < GT; g++) {
-                const float* qg = qrow + g * HD + c * 4;
-                s[g] = fmaf(qg[0], kv.x, s[g]);
-                s[g] = fmaf(qg[1], kv.y, s[g]);
-                s[g] = fmaf(qg[2], kv.z, s[g]);
-                s[g] = fmaf(qg[3], kv.w, s[g]);
-            }
+        for (int rr = 0; rr < 4; rr++) {
+            const float v = (s0[rr] + s1[rr]) * a.scale;   // scale after the dot, like the reference
+            sc[rr] = (kfirst + rr <= plim) ? v : -INFINITY;
+            mx = fmaxf(mx, sc[rr]);
         }
-        const bool valid = k0 + lane < kend;
-        // ---- 3. online softmax
-        float pr[GT];
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx > m)) {   // the running maximum of some column rises: rescale (rare after the first pages)
+            const float mn = fmaxf(m, mx);
+            const float alpha = mn == -INFINITY ? 1.f : expf(m - mn);
+            lsum *= alpha;
 #pragma unroll
-        for (int g = 0; g < GT; g++) {
-            const float sc = valid ? s[g] * a.scale : -INFINITY;
-            const float mn = fmaxf(m[g], wmax(sc));
-            const float e = valid ? expf(sc - mn) : 0.f;
-            const float alpha = expf(m[g] - mn);
-            l[g] = l[g] * alpha + wsum(e);
+            for (int n = 0; n < NV; n++)
 #pragma unroll
-            for (int d = 0; d < DPL; d++) acc[g][d] *= alpha;
-            m[g] = mn;
-            pr[g] = e;
+                for (int e = 0; e < 4; e++) oacc[n][e] *= alpha;
+            m = mn;
         }
-        // ---- 4. stage the value rows over the keys, lane = output dimension
+        float p[4];
 #pragma unroll
-        for (int i = 0; i < CPR; i++) {
-            const int idx = i * 64 + lane;
-            const int key = idx / CPR, c = idx % CPR;
-            const int ta = k0 + key;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ta < kend) {
-                const long row = table ? (long)table[ta / a.bs] * a.bs + (ta % a.bs) : (long)ta;
-                v = load4(pv + row * rowstride + c * 4);
-            }
-            *reinterpret_cast<float4*>(tile + key * STRIDE + c * 4) = v;
+        for (int rr = 0; rr < 4; rr++) {
+            p[rr] = expf(sc[rr] - m);   // masked keys: exp(-inf) = 0; column with nothing visible: m = -inf -> nan-safe below
+            if (m == -INFINITY) p[rr] = 0.f;
+            lsum += p[rr];
         }
+        // ---- O^T += V^T P^T
 #pragma unroll
-        for (int j = 0; j < 64; j++) {
-            float vj[DPL];
+        for (int n = 0; n < NV; n++)
 #pragma unroll
-            for (int d = 0; d < DPL; d++) {
-                const int dim = lane + 64 * d;
-                vj[d] = dim < HD ? tile[j * STRIDE + dim] : 0.f;
+            for (int s = 0; s < 4; s++) {
+                oacc[n][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.v[n][s].x, p[s], oacc[n][0], 0, 0, 0);
+                oacc[n][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.v[n][s].y, p[s], oacc[n][1], 0, 0, 0);
+                oacc[n][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.v[n][s].z, p[s], oacc[n][2], 0, 0, 0);
+                oacc[n][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.v[n][s].w, p[s], oacc[n][3], 0, 0, 0);
             }
-#pragma unroll
-            for (int g = 0; g < GT; g++) {
-                const float pj = lane_bcast(pr[g], j);
-#pragma unroll
-                for (int d = 0; d < DPL; d++) acc[g][d] = fmaf(pj, vj[d], acc[g][d]);
-            }
+    };
+
+    // ---- page loop: the next page's loads are always in flight while the current
+    // page is consumed.  Prefetches past the slice re-read its last page (an L2 hit).
+    PageRegs<HD, KVT> ra, rb;
+    if (pg_begin < pg_end) {
+        load_page<HD, KVT>(ra, kbase(pg_begin), vbase(pg_begin), live_of(pg_begin), rs, lane);
+        for (int pg = pg_begin; pg < pg_end; pg += 2) {
+            load_page<HD, KVT>(rb, kbase(pg + 1), vbase(pg + 1), live_of(pg + 1), rs, lane);
+            compute(ra, pg);
+            load_page<HD, KVT>(ra, kbase(pg + 2), vbase(pg + 2), live_of(pg + 2), rs, lane);
+            if (pg + 1 < pg_end) compute(rb, pg + 1);
         }
     }
 
-    // ---- results
+    // ---- results: lane (col x, g) holds dims 64n + 16g + 4r + e of its column
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (!cvalid) return;
+    const int h = h0 + chead;
     if (a.nsplit > 1) {
-        float* pa = a.part_acc + (size_t)item * GT * HD;
-        float* pm = a.part_ml + (size_t)item * GT * 2;
+        float* pa = a.part_acc + (((size_t)tcol * a.H + h) * a.nsplit + split) * HD;
 #pragma unroll
-        for (int g = 0; g < GT; g++) {
+        for (int n = 0; n < NV; n++)
 #pragma unroll
-            for (int d = 0; d < DPL; d++) {
-                const int dim = lane + 64 * d;
-                if (dim < HD) pa[g * HD + dim] = acc[g][d];
+            for (int rr = 0; rr < 4; rr++) {
+                const int d = 64 * n + 16 * g + 4 * rr;
+                if (d < HD)
+                    *reinterpret_cast<float4*>(pa + d) =
+                        make_float4(oacc[n][0][rr], oacc[n][1][rr], oacc[n][2][rr], oacc[n][3][rr]);
             }
-            if (lane == 0) {
-                pm[2 * g] = m[g];
-                pm[2 * g + 1] = l[g];
-            }
+        if (g == 0) {
+            float* pm = a.part_ml + (((size_t)tcol * a.H + h) * a.nsplit + split) * 2;
+            pm[0] = m;
+            pm[1] = lsum;
         }
         return;
     }
+    const float inv = 1.0f / lsum;
 #pragma unroll
-    for (int g = 0; g < GT; g++) {
-        const float inv = 1.0f / l[g];
+    for (int n = 0; n < NV; n++) {
+        const int d0 = 64 * n + 16 * g;
+        if (d0 < HD) {
+            float o[16];
 #pragma unroll
-        for (int d = 0; d < DPL; d++) {
-            const int dim = lane + 64 * d;
-            const float o = acc[g][d] * inv;
-            if (dim < HD) {
-                if (a.out_f32) a.out_f32[((size_t)t * a.H + h0 + g) * HD + dim] = o;
-                tile[g * HD + dim] = o;
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[4 * rr + e] = oacc[n][e][rr] * inv;
+            if (a.out_f32) {
+                float* dst = a.out_f32 + ((size_t)tcol * a.H + h) * HD + d0;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+                    *reinterpret_cast<float4*>(dst + 4 * rr) = make_float4(o[4 * rr], o[4 * rr + 1], o[4 * rr + 2], o[4 * rr + 3]);
             }
-        }
-    }
-    if (a.out_a16) {
-        // re-read 8 consecutive dims per lane and emit the hi/lo tile chunks
-        for (int c = lane; c < GT * HD / 8; c += 64) {
-            const int kk = h0 * HD + c * 8;
-            H8 hi, lo;
+            if (a.out_a16) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float x = fminf(fmaxf(tile[c * 8 + j], -65504.f), 65504.f);
-                hi.v[j] = __float2half_rn(x);
-                lo.v[j] = __float2half_rn(x - __half2float(hi.v[j]));
+                for (int half8 = 0; half8 < 2; half8++) {
+                    const int kk = h * HD + d0 + 8 * half8;
+                    H8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float xv = fminf(fmaxf(o[8 * half8 + j], -65504.f), 65504.f);
+                        hi.v[j] = __float2half_rn(xv);
+                        lo.v[j] = __float2half_rn(xv - __half2float(hi.v[j]));
+                    }
+                    const size_t tl = ((size_t)(tcol >> 4) * a.Kb_out + (kk >> 5)) * 2;
+                    const size_t off = (size_t)((tcol & 15) + 16 * ((kk >> 3) & 3)) * 8;
+                    *reinterpret_cast<H8*>(a.out_a16 + tl * TILE_HALVES + off) = hi;
+                    *reinterpret_cast<H8*>(a.out_a16 + (tl + 1) * TILE_HALVES + off) = lo;
+                }
             }
-            const size_t tl = ((size_t)(t >> 4) * a.Kb_out + (kk >> 5)) * 2;
-            const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8;
-            *reinterpret_cast<H8*>(a.out_a16 + tl * TILE_HALVES + off) = hi;
-            *reinterpret_cast<H8*>(a.out_a16 + (tl + 1) * TILE_HALVES + off) = lo;
         }
     }
 }
@@ -233,36 +288,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_paged_attn(AttnKArgs a) {
 // Merge the key-slice partials of each (token, head): thread = 8 consecutive dims.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_acc,
                                                       const float* __restrict__ part_ml, int T, int H, int HD,
-                                                      int GT, int nsplit, float* out_f32, __half* out_a16,
-                                                      int Kb_out) {
+                                                      int nsplit, float* out_f32, __half* out_a16, int Kb_out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = HD / 8;
     if (idx >= (long)T * H * c8) return;
     const int c = (int)(idx % c8);
-    const int h = (int)((idx / c8) % H);
-    const int t = (int)(idx / ((long)c8 * H));
-    const int NG = H / GT, hg = h / GT, g = h % GT;
-    const long item0 = ((long)t * NG + hg) * nsplit;
+    const long th = idx / c8;           // t * H + h
+    const int h = (int)(th % H);
+    const int t = (int)(th / H);
+    const float* ml = part_ml + th * nsplit * 2;
+    const float* pa = part_acc + th * nsplit * HD + c * 8;
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; s++) M = fmaxf(M, part_ml[((item0 + s) * GT + g) * 2]);
+    for (int s = 0; s < nsplit; s++) M = fmaxf(M, ml[2 * s]);
     float L = 0.f, o[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] = 0.f;
     for (int s = 0; s < nsplit; s++) {
-        const float* ml = part_ml + ((item0 + s) * GT + g) * 2;
-        const float w = expf(ml[0] - M);
-        L += ml[1] * w;
-        const float* pa = part_acc + ((item0 + s) * GT + g) * HD + c * 8;
-        const float4 a0 = *reinterpret_cast<const float4*>(pa);
-        const float4 a1 = *reinterpret_cast<const float4*>(pa + 4);
-        o[0] += a0.x * w; o[1] += a0.y * w; o[2] += a0.z * w; o[3] += a0.w * w;
-        o[4] += a1.x * w; o[5] += a1.y * w; o[6] += a1.z * w; o[7] += a1.w * w;
+        const float w = expf(ml[2 * s] - M);   // empty slices carry max = -inf -> weight 0
+        L = fmaf(ml[2 * s + 1], w, L);
+        const float4 a0 = *reinterpret_cast<const float4*>(pa + (size_t)s * HD);
+        const float4 a1 = *reinterpret_cast<const float4*>(pa + (size_t)s * HD + 4);
+        o[0] = fmaf(a0.x, w, o[0]); o[1] = fmaf(a0.y, w, o[1]); o[2] = fmaf(a0.z, w, o[2]); o[3] = fmaf(a0.w, w, o[3]);
+        o[4] = fmaf(a1.x, w, o[4]); o[5] = fmaf(a1.y, w, o[5]); o[6] = fmaf(a1.z, w, o[6]); o[7] = fmaf(a1.w, w, o[7]);
     }
     const float inv = 1.0f / L;
 #pragma unroll
     for (int j = 0; j < 8; j++) o[j] *= inv;
     if (out_f32) {
-        float* dst = out_f32 + ((size_t)t * H + h) * HD + c * 8;
+        float* dst = out_f32 + th * HD + c * 8;
         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
     }
@@ -271,9 +324,9 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
         H8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float x = fminf(fmaxf(o[j], -65504.f), 65504.f);
-            hi.v[j] = __float2half_rn(x);
-            lo.v[j] = __float2half_rn(x - __half2float(hi.v[j]));
+            const float xv = fminf(fmaxf(o[j], -65504.f), 65504.f);
+            hi.v[j] = __float2half_rn(xv);
+            lo.v[j] = __float2half_rn(xv - __half2float(hi.v[j]));
         }
         const size_t tl = ((size_t)(t >> 4) * Kb_out + (kk >> 5)) * 2;
         const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8;
@@ -283,53 +336,62 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ launch
-template <int HD, int GT, int WAVES>
-static void launch_cfg(const AttnKArgs& k, long items, int elem_bytes) {
-    const dim3 grid((unsigned)((items + WAVES - 1) / WAVES)), block(WAVES * 64);
+template <int HD>
+static void launch_hd(const AttnKArgs& k, long waves, int elem_bytes) {
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (elem_bytes == 4)
-        hipLaunchKernelGGL((k_paged_attn<HD, GT, WAVES, float>), grid, block, 0, rt().stream, k);
+        hipLaunchKernelGGL((k_paged_attn<HD, float>), grid, block, 0, rt().stream, k);
     else
-        hipLaunchKernelGGL((k_paged_attn<HD, GT, WAVES, __half>), grid, block, 0, rt().stream, k);
-}
-
-template <int HD, int WAVES>
-static void launch_hd(const AttnKArgs& k, int GT, long items, int elem_bytes) {
-    switch (GT) {
-        case 8: launch_cfg<HD, 8, WAVES>(k, items, elem_bytes); break;
-        case 4: launch_cfg<HD, 4, WAVES>(k, items, elem_bytes); break;
-        case 2: launch_cfg<HD, 2, WAVES>(k, items, elem_bytes); break;
-        default: launch_cfg<HD, 1, WAVES>(k, items, elem_bytes); break;
-    }
+        hipLaunchKernelGGL((k_paged_attn<HD, __half>), grid, block, 0, rt().stream, k);
 }
 
 extern "C" float nvllm_host_attn_scale(int head_dim);
 
+int attn_tokens_per_item(int H, int KVH) {
+    int gt = 1;
+    const int group = H / KVH;
+    while (gt < 16 && group % (gt * 2) == 0) gt *= 2;   // gcd(group, 16)
+    return 16 / gt;
+}
+
 void launch_paged_attention(const AttnArgs& a) {
     if (a.T <= 0) return;
-    const int group = a.H / a.KVH;
-    const int GT = (group == 8 || group == 4 || group == 2) ? group : 1;
+    const int CT = attn_tokens_per_item(a.H, a.KVH), GT = 16 / CT;
     const int NG = a.H / GT;
-    const long base_items = (long)a.T * NG;
-    const int tiles = cdiv(a.max_pos + 1, 64);
-    int nsplit = (int)((4096 + base_items - 1) / base_items);
-    if (nsplit > cdiv(tiles, 2)) nsplit = cdiv(tiles, 2);
+    // The kernel walks pages of 16 positions; a pool with another block size is
+    // addressed position by position through a page size of 1 ... not supported.
+    if (a.tables && a.pool.block_size != 16)
+        NVLLM_FATAL("paged attention supports block_size 16 (the driver's value), got %d", a.pool.block_size);
+    const long base_items = (long)a.n_runs * NG;
+    const int pages = (a.max_pos + 16) / 16;
+    static const int target_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 4096;
+    int nsplit = (int)((target_waves + base_items - 1) / base_items);
+    if (nsplit > (pages + 1) / 2) nsplit = (pages + 1) / 2;   // at least two pages per slice
     if (nsplit < 1) nsplit = 1;
-    const long items = base_items * nsplit;
+    const long waves = base_items * nsplit;
 
     AttnKArgs k;
     k.q = a.q;
     k.pool_k = a.pool.k;
     k.pool_v = a.pool.v;
     k.layer_off = (long)a.layer * a.pool.layer_stride;
-    k.bs = a.pool.block_size;
+    k.rowstride = (long)a.KVH * a.hd;
+    k.page = 16;
     k.pos = a.pos;
     k.pos0 = a.pos0;
     k.seq = a.seq;
     k.tbl_off = a.tbl_off;
     k.tables = a.tables;
-    k.T = a.T;
+    k.runs = (const int2*)a.runs;
+    k.n_runs = a.n_runs;
     k.H = a.H;
     k.KVH = a.KVH;
+    k.GT = GT;
+    k.CT = CT;
+    k.NG = NG;
+    k.group = a.H / a.KVH;
+    k.gt_shift = 0;
+    while ((1 << k.gt_shift) < GT) k.gt_shift++;
     k.nsplit = nsplit;
     k.scale = nvllm_host_attn_scale(a.hd);
     k.out_f32 = a.out_f32;
@@ -338,29 +400,31 @@ void launch_paged_attention(const AttnArgs& a) {
     k.part_acc = nullptr;
     k.part_ml = nullptr;
     if (nsplit > 1) {
-        float* part = (float*)ws_get(WS_ATT_PART, (size_t)items * GT * (a.hd + 2) * sizeof(float));
+        const size_t rows = (size_t)a.T * a.H * nsplit;
+        float* part = (float*)ws_get(WS_ATT_PART, rows * (a.hd + 2) * sizeof(float));
         k.part_acc = part;
-        k.part_ml = part + (size_t)items * GT * a.hd;
+        k.part_ml = part + rows * a.hd;
     }
     {
-        // algorithmic bytes: each (token, kv head) reads its keys and values once
-        const double kvb = (double)a.T * (a.max_pos + 1) * 0.5 * 2.0 * a.KVH * a.hd * a.pool.elem_bytes;
-        ProfScope ps(PC_ATTN, kvb + (double)a.T * a.H * a.hd * 8.0, 4.0 * a.T * (double)a.H * a.hd * (a.max_pos + 1) * 0.5);
+        // algorithmic bytes: each (sequence run, kv head) reads its keys and values once
+        const double kvb = (double)a.kv_positions * 2.0 * a.KVH * a.hd * a.pool.elem_bytes;
+        ProfScope ps(PC_ATTN, kvb + (double)a.T * a.H * a.hd * 8.0, 4.0 * (double)a.kv_positions * CT * a.H * a.hd);
         switch (a.hd) {
-            case 16: launch_hd<16, 4>(k, GT, items, a.pool.elem_bytes); break;
-            case 32: launch_hd<32, 4>(k, GT, items, a.pool.elem_bytes); break;
-            case 48: launch_hd<48, 4>(k, GT, items, a.pool.elem_bytes); break;
-            case 64: launch_hd<64, 4>(k, GT, items, a.pool.elem_bytes); break;
-            case 96: launch_hd<96, 2>(k, GT, items, a.pool.elem_bytes); break;
-            case 128: launch_hd<128, 2>(k, GT, items, a.pool.elem_bytes); break;
-            default: NVLLM_FATAL("head_dim %d is not supported (16, 32, 48, 64, 96, 128)", a.hd);
+            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes); break;
+            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes); break;
+            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes); break;
+            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes); break;
+            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes); break;
+            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes); break;
+            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes); break;
+            default: NVLLM_FATAL("head_dim %d is not supported (16, 32, 48, 64, 80, 96, 128)", a.hd);
         }
     }
     if (nsplit > 1) {
-        ProfScope ps(PC_ATTN_COMBINE, (double)items * GT * a.hd * 4.0, 0);
+        ProfScope ps(PC_ATTN_COMBINE, (double)a.T * a.H * nsplit * (a.hd + 2) * 4.0, 0);
         const long threads = (long)a.T * a.H * (a.hd / 8);
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, rt().stream,
-                           k.part_acc, k.part_ml, a.T, a.H, a.hd, GT, nsplit, a.out_f32, a.out_a16, k.Kb_out);
+                           k.part_acc, k.part_ml, a.T, a.H, a.hd, nsplit, a.out_f32, a.out_a16, k.Kb_out);
     }
 }
 

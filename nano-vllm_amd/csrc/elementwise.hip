@@ -125,9 +125,17 @@ __global__ __launch_bounds__(256) void k_rmsnorm(float* out_f32, __half* out_a16
     for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
         float4 v = *reinterpret_cast<const float4*>(xr + i);
         if (ksplit > 0) {
-            for (int s = 0; s < ksplit; s++) {
-                const float4 p = *reinterpret_cast<const float4*>(slabs + s * slab_stride + (size_t)ts * D + i);
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            // issue every slab load before the first add: a load-add chain would pay
+            // one L2 round trip per slab
+            for (int s0 = 0; s0 < ksplit; s0 += 8) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (s0 + u < ksplit)
+                        p[u] = *reinterpret_cast<const float4*>(slabs + (s0 + u) * slab_stride + (size_t)ts * D + i);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (s0 + u < ksplit) { v.x += p[u].x; v.y += p[u].y; v.z += p[u].z; v.w += p[u].w; }
             }
             // pass 2 re-reads the row, so the folded sum goes back to x in every mode
             // (rows named twice by `gather` would race; output rows are distinct)
@@ -322,10 +330,14 @@ __global__ __launch_bounds__(256) void k_rope_kv(float* __restrict__ q_out, floa
     KVT* vd = pool_v + layer_off + row * KD;
     for (int i = threadIdx.x; i < ND / 2; i += blockDim.x) {
         float2 v = reinterpret_cast<const float2*>(src)[i];
-        for (int s = 1; s < ksplit; s++) {
-            const float2 w = reinterpret_cast<const float2*>(src + s * slab_stride)[i];
-            v.x += w.x;
-            v.y += w.y;
+        for (int s0 = 1; s0 < ksplit; s0 += 8) {  // loads first, adds after (see k_rmsnorm)
+            float2 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (s0 + u < ksplit) w[u] = reinterpret_cast<const float2*>(src + (s0 + u) * slab_stride)[i];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (s0 + u < ksplit) { v.x += w[u].x; v.y += w[u].y; }
         }
         const int e = 2 * i;
         if (e < QD) {

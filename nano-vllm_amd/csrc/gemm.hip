@@ -79,18 +79,22 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     h8_t w[RW][NBW];
     h8_t ah[RA][TB], al[RA][TB];
 
-    // tile index (in units of 64 h8_t) of this wave's step s, clamped to its last step
-    auto kb_of = [&](int s) { return first + NW * min(s, max(nsteps - 1, 0)); };
+    // K-tile of this wave's step s
+    auto kb_of = [&](int s) { return first + NW * s; };
 
-    if (nsteps > 0) {
+    // Loads are issued only for steps that exist (wave-uniform branches): a clamped
+    // "harmless" re-load of the last tile would be real HBM traffic, since streamed
+    // weights are loaded non-temporally and do not stay in L2.
 #pragma unroll
-        for (int s = 0; s < RW; s++) {
+    for (int s = 0; s < RW; s++)
+        if (s < nsteps) {
             const int kb = kb_of(s);
 #pragma unroll
             for (int i = 0; i < NBW; i++) w[s][i] = __builtin_nontemporal_load(wp[i] + (size_t)kb * 64);
         }
 #pragma unroll
-        for (int s = 0; s < RA; s++) {
+    for (int s = 0; s < RA; s++)
+        if (s < nsteps) {
             const int kb = kb_of(s);
 #pragma unroll
             for (int j = 0; j < TB; j++) {
@@ -98,21 +102,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                 al[s][j] = ap[j][(size_t)kb * 128 + 64];
             }
         }
-        for (int s0 = 0; s0 < nsteps; s0 += RW) {
+    for (int s0 = 0; s0 < nsteps; s0 += RW) {
 #pragma unroll
-            for (int r = 0; r < RW; r++) {
-                const int s = s0 + r;
-                if (s < nsteps) {
+        for (int r = 0; r < RW; r++) {
+            const int s = s0 + r;
+            if (s < nsteps) {
 #pragma unroll
-                    for (int i = 0; i < NBW; i++)
+                for (int i = 0; i < NBW; i++)
 #pragma unroll
-                        for (int j = 0; j < TB; j++) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
-                        }
+                    for (int j = 0; j < TB; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
+                    }
+                if (s + RW < nsteps) {
                     const int kbw = kb_of(s + RW);
 #pragma unroll
                     for (int i = 0; i < NBW; i++) w[r][i] = __builtin_nontemporal_load(wp[i] + (size_t)kbw * 64);
+                }
+                if (s + RA < nsteps) {
                     const int kba = kb_of(s + RA);
 #pragma unroll
                     for (int j = 0; j < TB; j++) {
@@ -193,7 +200,8 @@ constexpr int GEMM_NW = 8;
 int gemm_pick_ksplit(int N, int K, int T) {
     const int NB = cdiv(N, 16), Kb = cdiv(K, 32);
     const int groups = cdiv(NB, GEMM_NBW) * cdiv(cdiv(T, 16), 4);
-    int ks = (384 + groups / 2) / groups;             // aim for a few hundred workgroups
+    static const int target_wgs = getenv("NVLLM_GEMM_WGS") ? atoi(getenv("NVLLM_GEMM_WGS")) : 384;
+    int ks = (target_wgs + groups / 2) / groups;      // aim for a few hundred workgroups
     const int ks_max = Kb / GEMM_NW > 0 ? Kb / GEMM_NW : 1;  // at least one K-step per wave
     if (ks > ks_max) ks = ks_max;
     if (ks < 1) ks = 1;

@@ -292,7 +292,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     const float eps = 1e-5f;  // model.c:361,388,396
 
     StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
-                               g_kv_manager.block_size);
+                               g_kv_manager.block_size, attn_tokens_per_item(H, KVH));
     const float2* rope = rope_table(p->rope_theta, hd, st.max_pos + 1);
     const KvPoolView pool = pool_view(&g_kv_manager, KVH, hd);
 
@@ -338,6 +338,9 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         at.tables = st.d_tables;
         at.T = T; at.H = H; at.KVH = KVH; at.hd = hd;
         at.max_pos = st.max_pos;
+        at.runs = st.d_runs;
+        at.n_runs = st.n_runs;
+        at.kv_positions = st.kv_positions;
         launch_paged_attention(at);
         // wo projection; its slabs are folded into x by the next norm      (model.c:385-388)
         WeightEntry wwo{lp.wo, D, QD, QD / 32, (long)(QD / 32) * TILE_HALVES, nullptr};

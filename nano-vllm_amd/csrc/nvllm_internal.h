@@ -192,8 +192,12 @@ struct AttnArgs {
     const int* tables;     // device, concatenated block tables (null: contiguous cache)
     int T, H, KVH, hd;
     int max_pos;           // largest position in the batch (host knowledge, for split sizing)
+    const int* runs;       // device (first token, count) pairs: runs of consecutive positions
+    int n_runs;            //   of one sequence, at most attn_tokens_per_item() tokens each
+    long kv_positions;     // sum over runs of (last position + 1): rows of K/V each kv head reads
 };
 void launch_paged_attention(const AttnArgs& a);
+int attn_tokens_per_item(int H, int KVH);
 
 void launch_embed(float* x, const __half* table, const int* tokens, int T, int D);
 void launch_swiglu(float* out, const float* g, const float* u, long n);

@@ -37,7 +37,7 @@ KvPoolView pool_view(const KVCacheManager* mgr, int n_kv_heads, int head_dim) {
 // pinned region and upload it with a single copy.
 StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids, int T,
                       const int* output_indices, int B, BlockTable** tables, const BlockTable* single,
-                      int pos0, int block_size) {
+                      int pos0, int block_size, int attn_ct) {
     StepArrays s{};
     s.T = T;
     s.B = B;
@@ -70,8 +70,23 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
     }
     size_t total_tbl = 0;
     for (int i = 0; i < n_seqs; i++) total_tbl += (size_t)need[i];
+    std::vector<int> runs;
+    s.kv_positions = 0;
+    if (attn_ct > 0) {
+        auto pos_of = [&](int t) { return pos_arr ? pos_arr[t] : pos0 + t; };
+        auto seq_of = [&](int t) { return seq_ids ? seq_ids[t] : 0; };
+        for (int t = 0; t < T;) {
+            int n = 1;
+            while (t + n < T && n < attn_ct && seq_of(t + n) == seq_of(t) && pos_of(t + n) == pos_of(t + n - 1) + 1) n++;
+            runs.push_back(t);
+            runs.push_back(n);
+            s.kv_positions += pos_of(t + n - 1) + 1;
+            t += n;
+        }
+    }
+    s.n_runs = (int)runs.size() / 2;
     const size_t n_ints = (size_t)(tokens ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) +
-                          (output_indices ? B : 0) + n_seqs + total_tbl + 64;
+                          (output_indices ? B : 0) + n_seqs + total_tbl + runs.size() + 64;
     int* host = pinned_ints(n_ints);
     int* dev = (int*)ws_get(WS_STEP, n_ints * sizeof(int));
     size_t o = 0;
@@ -104,6 +119,8 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
         }
         o += run;
     }
+    o = (o + 1) & ~(size_t)1;  // int2 alignment
+    s.d_runs = runs.empty() ? nullptr : put(runs.data(), runs.size());
     if (o > 0) HIP_CHECK(hipMemcpyAsync(dev, host, o * sizeof(int), hipMemcpyHostToDevice, rt().stream));
     return s;
 }
@@ -283,6 +300,8 @@ void multi_head_attention(float* out, float* q, float* key_cache, float* value_c
     (void)att;
     ensure_init();
     if (num_tokens <= 0) return;
+    StepArrays s = stage_step(nullptr, nullptr, nullptr, num_tokens, nullptr, 0, nullptr, nullptr, pos, 16,
+                              attn_tokens_per_item(n_heads, n_kv_heads));
     AttnArgs a{};
     a.q = q;
     a.out_f32 = out;
@@ -293,7 +312,10 @@ void multi_head_attention(float* out, float* q, float* key_cache, float* value_c
     a.H = n_heads;
     a.KVH = n_kv_heads;
     a.hd = head_dim;
-    a.max_pos = pos + num_tokens - 1;
+    a.max_pos = s.max_pos;
+    a.runs = s.d_runs;
+    a.n_runs = s.n_runs;
+    a.kv_positions = s.kv_positions;
     launch_paged_attention(a);
 }
 
@@ -305,7 +327,7 @@ void paged_attention(float* out, float* q, KVCacheManager* mgr, BlockTable* bloc
     ensure_init();
     if (num_tokens <= 0) return;
     StepArrays s = stage_step(nullptr, nullptr, nullptr, num_tokens, nullptr, 0, nullptr, block_table, pos,
-                              mgr->block_size);
+                              mgr->block_size, attn_tokens_per_item(n_heads, n_kv_heads));
     AttnArgs a{};
     a.q = q;
     a.out_f32 = out;
@@ -319,6 +341,9 @@ void paged_attention(float* out, float* q, KVCacheManager* mgr, BlockTable* bloc
     a.KVH = n_kv_heads;
     a.hd = head_dim;
     a.max_pos = s.max_pos;
+    a.runs = s.d_runs;
+    a.n_runs = s.n_runs;
+    a.kv_positions = s.kv_positions;
     launch_paged_attention(a);
 }
 
@@ -330,7 +355,7 @@ void paged_attention_batch(float* out, float* q, KVCacheManager* mgr, BlockTable
     ensure_init();
     if (num_tokens <= 0) return;
     StepArrays s = stage_step(nullptr, pos_arr, seq_ids, num_tokens, nullptr, 0, block_tables, nullptr, 0,
-                              mgr->block_size);
+                              mgr->block_size, attn_tokens_per_item(n_heads, n_kv_heads));
     AttnArgs a{};
     a.q = q;
     a.out_f32 = out;
@@ -345,6 +370,9 @@ void paged_attention_batch(float* out, float* q, KVCacheManager* mgr, BlockTable
     a.KVH = n_kv_heads;
     a.hd = head_dim;
     a.max_pos = s.max_pos;
+    a.runs = s.d_runs;
+    a.n_runs = s.n_runs;
+    a.kv_positions = s.kv_positions;
     launch_paged_attention(a);
 }
 

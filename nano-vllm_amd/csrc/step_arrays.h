@@ -15,15 +15,20 @@ struct StepArrays {
     int* d_out_idx;   // [B]
     int* d_tbl_off;   // [n_seqs]   start of each sequence's table inside d_tables
     int* d_tables;    // concatenated logical->physical block maps
+    int* d_runs;      // [n_runs][2] (first token, count): attention work items
+    int n_runs;
+    long kv_positions;
 };
 
 // Copies the arrays into the pinned ring, lays the block tables of the sequences
 // that occur in the batch end to end, and enqueues ONE host-to-HBM copy.
 // `tables` (indexed by seq id) or `single` (one table, positions pos0 + t) may be
-// null for operators that do not touch the pool.
+// null for operators that do not touch the pool.  attn_ct > 0 also cuts the batch into
+// attention work items: runs of at most attn_ct tokens of one sequence at
+// consecutive positions.
 StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids, int T,
                       const int* output_indices, int B, BlockTable** tables, const BlockTable* single,
-                      int pos0, int block_size);
+                      int pos0, int block_size, int attn_ct = 0);
 
 KvPoolView pool_view(const KVCacheManager* mgr, int n_kv_heads, int head_dim);
 
