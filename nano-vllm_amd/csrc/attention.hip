@@ -364,7 +364,7 @@ void launch_paged_attention(const AttnArgs& a) {
         NVLLM_FATAL("paged attention supports block_size 16 (the driver's value), got %d", a.pool.block_size);
     const long base_items = (long)a.n_runs * NG;
     const int pages = (a.max_pos + 16) / 16;
-    static const int target_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 4096;
+    static const int target_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 2048;
     int nsplit = (int)((target_waves + base_items - 1) / base_items);
     if (nsplit > (pages + 1) / 2) nsplit = (pages + 1) / 2;   // at least two pages per slice
     if (nsplit < 1) nsplit = 1;

@@ -104,6 +104,71 @@ void launch_embed(float* x, const __half* table, const int* tokens, int T, int D
     hipLaunchKernelGGL(k_embed, dim3(T), dim3(256), 0, rt().stream, x, table, tokens, D);
 }
 
+// Embedding gather fused with the first layer's input preparation: fp32 residual
+// row, the row times the first RMSNorm gain as fp16 hi/lo tiles, and the sum of
+// squares per 64-feature tile (the consumer projection turns those into 1/rms).
+__global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, __half* __restrict__ a16,
+                                                        float* __restrict__ ss, const __half* __restrict__ table,
+                                                        const int* __restrict__ tokens,
+                                                        const float* __restrict__ gain, int D, int ss_tiles) {
+    const int t = blockIdx.x;
+    const __half* row = table + (size_t)tokens[t] * D;
+    float* dst = x + (size_t)t * D;
+    const int Kb = (D + 31) >> 5;
+    for (int i = threadIdx.x * 8; i < ((D + 63) & ~63); i += blockDim.x * 8) {
+        float v[8], y[8], part = 0.f;
+        if (i < D) {   // D % 8 == 0
+            const Half8 h = *reinterpret_cast<const Half8*>(row + i);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v[j] = __half2float(h.v[j]);
+                y[j] = v[j] * gain[i + j];
+                part += v[j] * v[j];
+            }
+            *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            store_a16_8(a16, t, i, Kb, y);
+        }
+        // 8 consecutive threads cover one 64-feature tile
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if ((threadIdx.x & 7) == 0 && (i >> 6) < ss_tiles) ss[(size_t)t * ss_tiles + (i >> 6)] = part;
+    }
+}
+
+void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
+                           const float* gain, int T, int D) {
+    if (T <= 0) return;
+    if (D % 32) NVLLM_FATAL("embedding width %d is not a multiple of 32", D);
+    ProfScope ps(PC_EMBED, (double)T * D * 10, 0);
+    hipLaunchKernelGGL(k_embed_prescale, dim3(T), dim3(256), 0, rt().stream, x, a16, ss, table, tokens, gain, D,
+                       cdiv(D, 64));
+}
+
+// Compact the rows that produce logits: tile-order rows idx[r] -> rows r.
+__global__ __launch_bounds__(256) void k_gather_a16(__half* __restrict__ dst, float* __restrict__ dst_ss,
+                                                    const __half* __restrict__ src,
+                                                    const float* __restrict__ src_ss,
+                                                    const int* __restrict__ idx, int Kb, int ss_tiles) {
+    const int r = blockIdx.x;
+    const int t = idx[r];
+    for (int c = threadIdx.x; c < Kb * 4; c += blockDim.x) {   // 8-element chunks of the row
+        const int k = c * 8;
+        *reinterpret_cast<Half8*>(dst + a16_chunk(r, k, Kb, 0)) = *reinterpret_cast<const Half8*>(src + a16_chunk(t, k, Kb, 0));
+        *reinterpret_cast<Half8*>(dst + a16_chunk(r, k, Kb, 1)) = *reinterpret_cast<const Half8*>(src + a16_chunk(t, k, Kb, 1));
+    }
+    for (int j = threadIdx.x; j < ss_tiles; j += blockDim.x) dst_ss[(size_t)r * ss_tiles + j] = src_ss[(size_t)t * ss_tiles + j];
+}
+
+void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const float* src_ss, const int* idx, int B,
+                       int K, int ss_tiles) {
+    if (B <= 0) return;
+    ProfScope ps(PC_PACK, (double)B * K * 8.0, 0);
+    hipLaunchKernelGGL(k_gather_a16, dim3(B), dim3(256), 0, rt().stream, dst, dst_ss, src, src_ss, idx, cdiv(K, 32),
+                       ss_tiles);
+}
+
 // ------------------------------------------------------------------ RMSNorm
 // One workgroup per output row.  Pass 1: (optionally) fold in the split-K slabs of
 // the previous projection, x += sum_s slab[s], and accumulate the sum of squares;

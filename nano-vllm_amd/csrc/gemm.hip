@@ -1,26 +1,45 @@
 // gemm.hip -- projections: out[T, N] = act[T, K] x W[N, K]^T with fp16 weights
 // streamed once from HBM in tile order, fp32 activations carried as fp16 hi/lo
-// tile pairs, fp32 accumulation on the matrix cores.
+// tile pairs, fp32 accumulation on the matrix cores, and the element-wise work
+// that follows each projection fused into its epilogue.
 //
 // Shape of the problem at decode: T <= 64 tokens, so every weight byte is used
 // for only 2*T flops and the kernel is bound by how fast the weights stream.
 // Work decomposition (one launch per projection):
-//   grid.x  groups of NBW 16-row blocks of W (NBW*16 output features)
-//   grid.y  split of K across workgroups (partial sums go to slabs, summed by
-//           the consumer kernel) -- only where the grid would otherwise be small
+//   grid.x  tiles of NBW 16-row blocks of W (64 output features)
+//   grid.y  split of K across workgroups, used where the grid would otherwise be
+//           too small to keep every CU streaming
 //   grid.z  groups of TB*16 tokens (prefill: weights re-read from L2/MALL)
 //   inside a workgroup the NW waves take the K-steps round-robin, each with all
 //   NBW row blocks, and their accumulators are summed through LDS at the end.
 // Per K-step (32 k) a wave loads NBW weight tiles (1 KiB each, one fully
-// coalesced dwordx4 per lane, HBM) and 2*TB activation tiles (L2), and issues
-// 2*NBW*TB v_mfma_f32_16x16x32_f16.  Weight loads run RW steps ahead, activation
-// loads RA steps ahead, in register rings.
+// coalesced dwordx4 per lane, non-temporal) and 2*TB activation tiles (L2), and
+// issues 2*NBW*TB v_mfma_f32_16x16x32_f16.  Weight loads run RW steps ahead,
+// activation loads RA steps ahead, in register rings.
+//
+// Split-K is closed INSIDE the launch: every K-slice writes its partial tile to a
+// slab with write-through (sc1) stores, drains them, and one lane takes a ticket
+// from a per-tile counter; the workgroup that draws the last ticket acquires,
+// adds the slabs in slice order (so the sum does not depend on who arrived last)
+// and runs the epilogue.  That removes a kernel boundary and a slab re-read per
+// projection, and lets the epilogue see complete sums:
+//   F32         logits (scaled by the token's 1/rms)
+//   SWIGLU_A16  silu(gate) * up             -> fp16 hi/lo tiles for w_down
+//   RESID_A16   x += result; x * next_gain  -> tiles for the next projection,
+//               plus per-tile sums of x^2 from which the consumer forms 1/rms
+//   ROPE_KV     rotate q,k; q -> fp32 rows for attention; k,v -> block pool
+// RMSNorm is thereby split in two: the producer stores x*g (no reduction needed),
+// the consumer multiplies its result by 1/rms (a per-token scalar commutes with
+// the projection).
+#include <vector>
+
 #include "nvllm_internal.h"
 
 namespace nvllm {
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const __half* W;
@@ -31,26 +50,80 @@ struct GemmArgs {
     int Tb;
     int N, T;
     int kb_per_split;
-    float* out;       // F32: [T, ldo]; SLAB: slabs[ks][Tpad][N] (ldo == N)
-    int ldo;
-    long slab_stride;
-    __half* a16_out;  // SWIGLU: tiles of [T, N/2]
-    int Kb_out;
+    int ksplit;
+    float* slab;      // [tile][slice][round][item] float4
+    unsigned* counters;
+    unsigned long long* stamps;   // diagnostic builds only (-DGEMM_STAMPS): [wg][wave][8] shader clocks
+    GemmEpilogue e;
 };
+
+#ifdef GEMM_STAMPS
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if (p.stamps && lane == 0) {                                                               \
+            const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    \
+            p.stamps[((size_t)wg * NW + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime();           \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ float silu_mul(float g, float u) {
     // reference layers.c:156-158: g / (1 + expf(-g)) * u
     return __fmul_rn(__fdiv_rn(g, __fadd_rn(1.0f, expf(-g))), u);
 }
 
-__device__ __forceinline__ f4_t f4_add(f4_t a, f4_t b) { return a + b; }
+__device__ __forceinline__ void split16_4(const float* y, __half* hi, __half* lo) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float c = fminf(fmaxf(y[r], -65504.f), 65504.f);
+        hi[r] = __float2half_rn(c);
+        lo[r] = __float2half_rn(c - __half2float(hi[r]));
+    }
+}
 
-template <int NBW, int TB, int NW, int EPI>
+// store 4 consecutive k of token t into hi/lo tiles (n % 4 == 0)
+__device__ __forceinline__ void store_a16_4(__half* a16, int Kb_out, int t, int n, const float* y) {
+    alignas(8) __half hi[4], lo[4];
+    split16_4(y, hi, lo);
+    const size_t tile = ((size_t)(t >> 4) * Kb_out + (n >> 5)) * 2;
+    const size_t off = (size_t)((t & 15) + 16 * ((n >> 3) & 3)) * 8 + (n & 7);
+    *reinterpret_cast<uint2*>(a16 + tile * TILE_HALVES + off) = *reinterpret_cast<uint2*>(hi);
+    *reinterpret_cast<uint2*>(a16 + (tile + 1) * TILE_HALVES + off) = *reinterpret_cast<uint2*>(lo);
+}
+
+template <typename KVT>
+__device__ __forceinline__ void kv_put4(KVT* dst, const float* y);
+template <>
+__device__ __forceinline__ void kv_put4<float>(float* dst, const float* y) {
+    *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+}
+template <>
+__device__ __forceinline__ void kv_put4<__half>(__half* dst, const float* y) {
+    alignas(8) __half h[4] = {__float2half_rn(y[0]), __float2half_rn(y[1]), __float2half_rn(y[2]), __float2half_rn(y[3])};
+    *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(h);
+}
+
+template <int NBW, int TB, int NW, int EPI, typename KVT>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
-    constexpr int RW = 4;  // weight ring depth (K-steps in flight)
-    constexpr int RA = 2;  // activation ring depth
+#ifndef GEMM_RW
+#define GEMM_RW 4
+#endif
+#ifndef GEMM_RA
+#define GEMM_RA 2
+#endif
+    constexpr int RW = GEMM_RW;        // weight ring depth (K-steps in flight)
+    constexpr int RA = GEMM_RA;        // activation ring depth
+    constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
+    constexpr int ITEMS = 2 * TB * 64; // float4 results per round
+    constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
     __shared__ f4_t red[NW][2][TB][64];
+    __shared__ float s_rinv[TB * 16];
+    __shared__ float s_part[(NW * 64) / (TB * 16)][TB * 16];
+    __shared__ float s_ss[2][TB * 16];
+    __shared__ unsigned s_ticket;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,6 +134,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     const int first = kb_begin + wave;
     const int nsteps = first < kb_end ? (kb_end - first + NW - 1) / NW : 0;
 
+    STAMP(0);
     const h8_t* wp[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; i++)
@@ -78,13 +152,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 
     h8_t w[RW][NBW];
     h8_t ah[RA][TB], al[RA][TB];
-
-    // K-tile of this wave's step s
     auto kb_of = [&](int s) { return first + NW * s; };
 
     // Loads are issued only for steps that exist (wave-uniform branches): a clamped
-    // "harmless" re-load of the last tile would be real HBM traffic, since streamed
-    // weights are loaded non-temporally and do not stay in L2.
+    // re-load of the last tile would be real HBM traffic, since streamed weights are
+    // loaded non-temporally and do not stay in L2.
 #pragma unroll
     for (int s = 0; s < RW; s++)
         if (s < nsteps) {
@@ -102,6 +174,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                 al[s][j] = ap[j][(size_t)kb * 128 + 64];
             }
         }
+    // 1/rms of this token group, from the producer's per-tile sums of squares: every
+    // thread sums a slice of one token's tiles (independent loads, issued while the
+    // first weight tiles are in flight); the slices meet in LDS before the epilogue.
+    if (p.e.ss_in != nullptr) {
+        constexpr int PARTS = (NW * 64) / (TB * 16);
+        const int tl = threadIdx.x % (TB * 16), part = threadIdx.x / (TB * 16);
+        const int t = min(tb0 * 16 + tl, p.T - 1);
+        const int src = p.e.ss_gather ? p.e.ss_gather[t] : t;
+        const float* sp = p.e.ss_in + (size_t)src * p.e.ss_tiles;
+        float ss = 0.f;
+        for (int j = part; j < p.e.ss_tiles; j += PARTS) ss += sp[j];
+        s_part[part][tl] = ss;
+    }
+    STAMP(1);
     for (int s0 = 0; s0 < nsteps; s0 += RW) {
 #pragma unroll
         for (int r = 0; r < RW; r++) {
@@ -114,12 +200,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
                     }
-                if (s + RW < nsteps) {
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+                if (GEMM_ABL != 2 && s + RW < nsteps) {
                     const int kbw = kb_of(s + RW);
 #pragma unroll
                     for (int i = 0; i < NBW; i++) w[r][i] = __builtin_nontemporal_load(wp[i] + (size_t)kbw * 64);
                 }
-                if (s + RA < nsteps) {
+                if (GEMM_ABL != 1 && s + RA < nsteps) {
                     const int kba = kb_of(s + RA);
 #pragma unroll
                     for (int j = 0; j < TB; j++) {
@@ -131,76 +220,216 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         }
     }
 
-    // ---- sum the waves' partial tiles through LDS, two row blocks per round ----
-    const int Tlim = p.T;
+    STAMP(2);
+    // ---- 1. sum the waves' partial tiles through LDS, two row blocks per round.
+    // Afterwards thread `e` (item e = threadIdx.x + q * NW*64) owns, per round h, the
+    // float4 for token t(e) and features n(h, e) .. n+3.
+    f4_t v[ROUNDS][IPT];
 #pragma unroll
-    for (int h = 0; h < NBW / 2; h++) {
+    for (int h = 0; h < ROUNDS; h++) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int j = 0; j < TB; j++) red[wave][i][j][lane] = acc[2 * h + i][j];
         __syncthreads();
-        if (EPI == GemmEpilogue::SWIGLU_A16) {
-            // even row block = gate, odd = up (interleaved storage): one hidden block
-            const int hid0 = ((nb0 + 2 * h) >> 1) * 16;
-            for (int e = threadIdx.x; e < TB * 64; e += NW * 64) {
-                const int j = e >> 6, l = e & 63;
-                f4_t g = red[0][0][j][l], u = red[0][1][j][l];
 #pragma unroll
-                for (int wv = 1; wv < NW; wv++) {
-                    g = f4_add(g, red[wv][0][j][l]);
-                    u = f4_add(u, red[wv][1][j][l]);
-                }
-                const int t = (tb0 + j) * 16 + (l & 15);
-                const int n = hid0 + 4 * (l >> 4);
-                if (t < Tlim && n < (p.N >> 1) && tb0 + j < p.Tb) {
-                    alignas(8) __half hi[4], lo[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float y = silu_mul(g[r], u[r]);
-                        const float c = fminf(fmaxf(y, -65504.f), 65504.f);
-                        hi[r] = __float2half_rn(c);
-                        lo[r] = __float2half_rn(c - __half2float(hi[r]));
-                    }
-                    const size_t tile = ((size_t)(t >> 4) * p.Kb_out + (n >> 5)) * 2;
-                    const size_t off = (size_t)((t & 15) + 16 * ((n >> 3) & 3)) * 8 + (n & 7);
-                    *reinterpret_cast<uint2*>(p.a16_out + tile * TILE_HALVES + off) = *reinterpret_cast<uint2*>(hi);
-                    *reinterpret_cast<uint2*>(p.a16_out + (tile + 1) * TILE_HALVES + off) = *reinterpret_cast<uint2*>(lo);
-                }
-            }
-        } else {
-            float* dst = p.out + (EPI == GemmEpilogue::SLAB ? (size_t)blockIdx.y * p.slab_stride : 0);
-            for (int e = threadIdx.x; e < 2 * TB * 64; e += NW * 64) {
+        for (int q = 0; q < IPT; q++) {
+            const int e = threadIdx.x + q * NW * 64;
+            f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
+            if (e < ITEMS) {
                 const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                f4_t v = red[0][i][j][l];
+                sum = red[0][i][j][l];
 #pragma unroll
-                for (int wv = 1; wv < NW; wv++) v = f4_add(v, red[wv][i][j][l]);
-                const int t = (tb0 + j) * 16 + (l & 15);
-                const int n = (nb0 + 2 * h + i) * 16 + 4 * (l >> 4);
-                if (t < Tlim && tb0 + j < p.Tb && nb0 + 2 * h + i < p.NB) {
-                    float* o = dst + (size_t)t * p.ldo + n;
-                    if (n + 3 < p.N && (p.ldo & 3) == 0) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                for (int wv = 1; wv < NW; wv++) sum += red[wv][i][j][l];
+            }
+            v[h][q] = sum;
+        }
+    }
+
+    STAMP(3);
+    // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
+    const unsigned tile_id = blockIdx.z * gridDim.x + blockIdx.x;
+    if (p.ksplit > 1) {
+        float* my = p.slab + ((size_t)tile_id * p.ksplit + blockIdx.y) * (ROUNDS * ITEMS * 4);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, ROUNDS * ITEMS * 16, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = threadIdx.x + q * NW * 64;
+                if (e < ITEMS)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[h][q]), rs, (h * ITEMS + e) * 16, 0,
+                                                           /*sc1: write through*/ 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        STAMP(4);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        STAMP(5);
+        if (s_ticket != (unsigned)p.ksplit - 1) return;     // not the last slice of this tile
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* base = p.slab + (size_t)tile_id * p.ksplit * (ROUNDS * ITEMS * 4);
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = threadIdx.x + q * NW * 64;
+                f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
+                if (e < ITEMS) {
+                    for (int s0 = 0; s0 < p.ksplit; s0 += 8) {   // loads first, adds after, in slice order
+                        f4_t part[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (s0 + u < p.ksplit)
+                                part[u] = *reinterpret_cast<const f4_t*>(base + ((size_t)(s0 + u) * ROUNDS * ITEMS + h * ITEMS + e) * 4);
+#pragma unroll
+                        for (int u = 0; u < 8; u++)
+                            if (s0 + u < p.ksplit) sum += part[u];
+                    }
+                }
+                v[h][q] = sum;
+            }
+    }
+
+    STAMP(6);
+    // ---- 3. epilogue on complete sums
+    const GemmEpilogue& ep = p.e;
+    if (ep.ss_in != nullptr) {
+        constexpr int PARTS = (NW * 64) / (TB * 16);
+        __syncthreads();
+        if (threadIdx.x < TB * 16) {
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
+            s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
+        }
+        __syncthreads();
+    }
+    float ssq[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; q++) ssq[q] = 0.f;
+#pragma unroll
+    for (int h = 0; h < ROUNDS; h++) {
+        if (EPI == GemmEpilogue::SWIGLU_A16) {
+            // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads:
+            // swap through LDS so that the i = 0 thread has both
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = threadIdx.x + q * NW * 64;
+                if (e < ITEMS) red[0][(e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const int e = threadIdx.x + q * NW * 64;
+            if (e >= ITEMS) continue;
+            const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+            const int tl = j * 16 + (l & 15);
+            const int t = tb0 * 16 + tl;
+            const int nb = nb0 + 2 * h + i;
+            const int n = nb * 16 + 4 * (l >> 4);
+            const bool live = t < p.T && tb0 + j < p.Tb && nb < p.NB;
+            const float rinv = ep.ss_in ? s_rinv[tl] : 1.0f;
+            float y[4] = {v[h][q][0] * rinv, v[h][q][1] * rinv, v[h][q][2] * rinv, v[h][q][3] * rinv};
+            if (EPI == GemmEpilogue::F32) {
+                if (live) {
+                    float* o = ep.out + (size_t)t * ep.ldo + n;
+                    if (n + 3 < p.N && (ep.ldo & 3) == 0) {
+                        *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; r++)
-                            if (n + r < p.N) o[r] = v[r];
+                            if (n + r < p.N) o[r] = y[r];
+                    }
+                }
+            } else if (EPI == GemmEpilogue::SWIGLU_A16) {
+                if (i == 0 && live) {
+                    const f4_t u = red[0][1][j][l];
+                    float z[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], u[r] * rinv);
+                    const int hid = (nb >> 1) * 16 + 4 * (l >> 4);
+                    store_a16_4(ep.a16_out, ep.Kb_out, t, hid, z);
+                }
+            } else if (EPI == GemmEpilogue::RESID_A16) {
+                if (live) {
+                    float* xr = ep.x + (size_t)t * p.N + n;
+                    const float4 xo = *reinterpret_cast<const float4*>(xr);
+                    const float4 g = *reinterpret_cast<const float4*>(ep.gain_next + n);
+                    // residual add as the reference's accum(): x = x + branch (layers.c:163-168)
+                    const float xn[4] = {__fadd_rn(xo.x, y[0]), __fadd_rn(xo.y, y[1]), __fadd_rn(xo.z, y[2]), __fadd_rn(xo.w, y[3])};
+                    *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+                    const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
+                    store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
+                    ssq[q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
+                }
+            } else {  // ROPE_KV
+                if (live) {
+                    const int pos = ep.pos[t];
+                    if (n < ep.QD + ep.KD) {   // q or k: rotate the two pairs of this float4 (layers.c:118-141)
+                        const int d = (n < ep.QD ? n : n - ep.QD) % ep.hd;
+                        const float2* tab = ep.rope + (size_t)pos * (ep.hd >> 1) + (d >> 1);
+                        const float2 c0 = tab[0], c1 = tab[1];
+                        const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
+                        y[0] = __fsub_rn(__fmul_rn(a0, c0.x), __fmul_rn(b0, c0.y));
+                        y[1] = __fadd_rn(__fmul_rn(a0, c0.y), __fmul_rn(b0, c0.x));
+                        y[2] = __fsub_rn(__fmul_rn(a1, c1.x), __fmul_rn(b1, c1.y));
+                        y[3] = __fadd_rn(__fmul_rn(a1, c1.y), __fmul_rn(b1, c1.x));
+                    }
+                    if (n < ep.QD) {
+                        *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
+                    } else if (t < ep.write_limit) {
+                        const int* table = ep.tables + ep.tbl_off[ep.seq[t]];
+                        const long row = (long)table[pos / ep.bs] * ep.bs + (pos % ep.bs);
+                        const bool is_k = n < ep.QD + ep.KD;
+                        const int c = is_k ? n - ep.QD : n - ep.QD - ep.KD;
+                        KVT* dst = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off + row * ep.KD + c;
+                        kv_put4<KVT>(dst, y);
                     }
                 }
             }
         }
     }
+    if (EPI == GemmEpilogue::RESID_A16) {
+        // per-token sum of x^2 over this tile's 64 features: over the 4 lane groups
+        // (l>>4), then over i (two halves of the workgroup)
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            float s = ssq[q];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const int e = threadIdx.x + q * NW * 64;
+            if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < TB * 16) {
+            const int t = tb0 * 16 + threadIdx.x;
+            if (t < p.T) ep.ss_out[(size_t)t * gridDim.x + blockIdx.x] = s_ss[0][threadIdx.x] + s_ss[1][threadIdx.x];
+        }
+    }
+    STAMP(7);
 }
 
 // ------------------------------------------------------------------ launch
 constexpr int GEMM_NBW = 4;
 constexpr int GEMM_NW = 8;
 
+int gemm_feature_tiles(int N) { return cdiv(cdiv(N, 16), GEMM_NBW); }
+
 int gemm_pick_ksplit(int N, int K, int T) {
     const int NB = cdiv(N, 16), Kb = cdiv(K, 32);
     const int groups = cdiv(NB, GEMM_NBW) * cdiv(cdiv(T, 16), 4);
-    static const int target_wgs = getenv("NVLLM_GEMM_WGS") ? atoi(getenv("NVLLM_GEMM_WGS")) : 384;
+    static const int target_wgs = getenv("NVLLM_GEMM_WGS") ? atoi(getenv("NVLLM_GEMM_WGS")) : 256;
     int ks = (target_wgs + groups / 2) / groups;      // aim for a few hundred workgroups
     const int ks_max = Kb / GEMM_NW > 0 ? Kb / GEMM_NW : 1;  // at least one K-step per wave
     if (ks > ks_max) ks = ks_max;
@@ -209,18 +438,40 @@ int gemm_pick_ksplit(int N, int K, int T) {
     return cdiv(Kb, per);
 }
 
-template <int TB>
-static void launch_tb(const GemmArgs& a, int epi, dim3 grid) {
+#ifdef GEMM_STAMPS
+static unsigned long long* g_last_stamps = nullptr;
+static int g_last_stamp_wgs = 0;
+extern "C" int nvllm_debug_dump_stamps(const char* path) {
+    if (!g_last_stamps) return -1;
+    std::vector<unsigned long long> h((size_t)g_last_stamp_wgs * 64);
+    HIP_CHECK(hipMemcpy(h.data(), g_last_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    FILE* f = fopen(path, "wb");
+    fwrite(&g_last_stamp_wgs, 4, 1, f);
+    fwrite(h.data(), 8, h.size(), f);
+    fclose(f);
+    return g_last_stamp_wgs;
+}
+#endif
+
+// arrival counters: zero when allocated, every launch leaves them zero again
+static unsigned* g_counters = nullptr;
+constexpr int MAX_COUNTERS = 1 << 16;
+
+template <int TB, typename KVT>
+static void launch_tb(const GemmArgs& a, dim3 grid) {
     const dim3 block(GEMM_NW * 64);
-    switch (epi) {
+    switch (a.e.kind) {
         case GemmEpilogue::F32:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::F32>), grid, block, 0, rt().stream, a);
+            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, rt().stream, a);
             break;
-        case GemmEpilogue::SLAB:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SLAB>), grid, block, 0, rt().stream, a);
+        case GemmEpilogue::SWIGLU_A16:
+            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, rt().stream, a);
+            break;
+        case GemmEpilogue::RESID_A16:
+            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, rt().stream, a);
             break;
         default:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16>), grid, block, 0, rt().stream, a);
+            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, rt().stream, a);
             break;
     }
 }
@@ -228,6 +479,11 @@ static void launch_tb(const GemmArgs& a, int epi, dim3 grid) {
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
                 const GemmEpilogue& epi, int force_ksplit, int prof_cls) {
     if (T <= 0 || N <= 0) return 1;
+    ensure_init();
+    if (!g_counters) {
+        HIP_CHECK(hipMalloc((void**)&g_counters, MAX_COUNTERS * sizeof(unsigned)));
+        HIP_CHECK(hipMemsetAsync(g_counters, 0, MAX_COUNTERS * sizeof(unsigned), rt().stream));
+    }
     GemmArgs a;
     a.W = tiles;
     a.nb_stride = w.nb_stride;
@@ -237,27 +493,58 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     a.Tb = cdiv(T, 16);
     a.N = N;
     a.T = T;
-    int ks = 1;
-    if (epi.kind == GemmEpilogue::SLAB) ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, w.K, T);
+    a.e = epi;
+    const int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
+    const int tiles_n = cdiv(a.NB, GEMM_NBW), tiles_t = cdiv(a.Tb, TB);
+    int ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, w.K, T);
+    if ((long)tiles_n * tiles_t > MAX_COUNTERS) ks = 1;
     a.kb_per_split = cdiv(a.Kb, ks);
     ks = cdiv(a.Kb, a.kb_per_split);
-    a.out = epi.out;
-    a.ldo = epi.kind == GemmEpilogue::SLAB ? N : epi.ldo;
-    a.slab_stride = (long)cdiv(T, 16) * 16 * N;
-    a.a16_out = epi.a16_out;
-    a.Kb_out = cdiv(N / 2, 32);
-    if (epi.kind == GemmEpilogue::SWIGLU_A16 && ((N / 2) % 32 != 0 || a.NB % 2 != 0))
-        NVLLM_FATAL("fused gate/up projection needs hidden_dim %% 32 == 0, got %d", N / 2);
-
-    const int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
-    const dim3 grid(cdiv(a.NB, GEMM_NBW), ks, cdiv(a.Tb, TB));
-    const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 +
-                         (double)T * N * (epi.kind == GemmEpilogue::SWIGLU_A16 ? 2.0 : 4.0 * ks);
+    a.ksplit = ks;
+    a.counters = g_counters;
+    a.stamps = nullptr;
+#ifdef GEMM_STAMPS
+    {
+        static unsigned long long* g_stamps = nullptr;
+        static const char* want = getenv("NVLLM_STAMP_CLASS");
+        if (!g_stamps) { HIP_CHECK(hipMalloc((void**)&g_stamps, 4096 * 8 * 8 * 8)); HIP_CHECK(hipMemsetAsync(g_stamps, 0, 4096 * 8 * 8 * 8, rt().stream)); }
+        if (want && atoi(want) == prof_cls && tiles_n * tiles_t * ks <= 4096) { a.stamps = g_stamps; g_last_stamps = g_stamps; g_last_stamp_wgs = tiles_n * tiles_t * ks; }
+    }
+#endif
+    a.slab = nullptr;
+    if (ks > 1) {
+        const size_t tile_bytes = (size_t)(GEMM_NBW / 2) * 2 * TB * 64 * 16;
+        a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles_n * tiles_t * ks * tile_bytes);
+    }
+    if (epi.kind == GemmEpilogue::SWIGLU_A16) {
+        if ((N / 2) % 32 != 0 || a.NB % 2 != 0) NVLLM_FATAL("fused gate/up projection needs hidden_dim %% 32 == 0, got %d", N / 2);
+        a.e.Kb_out = cdiv(N / 2, 32);
+    } else if (epi.kind == GemmEpilogue::RESID_A16) {
+        if (N % 32 != 0) NVLLM_FATAL("fused residual epilogue needs a width that is a multiple of 32, got %d", N);
+        a.e.Kb_out = cdiv(N, 32);
+    }
+    const dim3 grid(tiles_n, ks, tiles_t);
+    const double out_bytes = epi.kind == GemmEpilogue::SWIGLU_A16 ? (double)T * N * 2.0
+                             : epi.kind == GemmEpilogue::RESID_A16 ? (double)T * N * 12.0
+                                                                   : (double)T * N * 4.0;
+    const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 + out_bytes;
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
-    if (TB == 1) launch_tb<1>(a, epi.kind, grid);
-    else if (TB == 2) launch_tb<2>(a, epi.kind, grid);
-    else launch_tb<4>(a, epi.kind, grid);
+    const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
+    if (kv16) {
+        if (TB == 1) launch_tb<1, __half>(a, grid);
+        else if (TB == 2) launch_tb<2, __half>(a, grid);
+        else launch_tb<4, __half>(a, grid);
+    } else {
+        if (TB == 1) launch_tb<1, float>(a, grid);
+        else if (TB == 2) launch_tb<2, float>(a, grid);
+        else launch_tb<4, float>(a, grid);
+    }
     return ks;
+}
+
+void gemm_release() {
+    if (g_counters) HIP_CHECK(hipFree(g_counters));
+    g_counters = nullptr;
 }
 
 // --------------------------------------------- raw fp32 weights (ops.h matmul)

@@ -288,7 +288,6 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     if (T > p->max_seq_len || B > p->max_seq_len) NVLLM_FATAL("batch of %d tokens exceeds the workspace (%d)", T, p->max_seq_len);
     const int D = p->dim, F = p->hidden_dim, hd = p->head_dim, H = p->n_heads, KVH = p->n_kv_heads;
     const int QD = H * hd, KD = KVH * hd, V = p->vocab_size;
-    const int Tpad = cdiv(T, 16) * 16;
     const float eps = 1e-5f;  // model.c:361,388,396
 
     StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
@@ -296,37 +295,34 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     const float2* rope = rope_table(p->rope_theta, hd, st.max_pos + 1);
     const KvPoolView pool = pool_view(&g_kv_manager, KVH, hd);
 
-    const int rows_x = T > B ? T : B;
-    __half* a16_x = (__half*)ws_get(WS_A16_X, a16_halves(rows_x, D) * sizeof(__half));
+    const int ssn = gemm_feature_tiles(D);   // 64-feature tiles of the residual width
+    __half* a16_x = (__half*)ws_get(WS_A16_X, a16_halves(T, D) * sizeof(__half));
     __half* a16_att = (__half*)ws_get(WS_A16_ATT, a16_halves(T, QD) * sizeof(__half));
     __half* a16_h = (__half*)ws_get(WS_A16_H, a16_halves(T, F) * sizeof(__half));
-    const int ks_qkv = gemm_pick_ksplit(QD + 2 * KD, D, T);
-    const int ks_wo = gemm_pick_ksplit(D, QD, T);
-    const int ks_dn = gemm_pick_ksplit(D, F, T);
-    size_t slab_floats = (size_t)ks_qkv * Tpad * (QD + 2 * KD);
-    slab_floats = std::max(slab_floats, (size_t)ks_wo * Tpad * D);
-    slab_floats = std::max(slab_floats, (size_t)ks_dn * Tpad * D);
-    float* slab = (float*)ws_get(WS_SLAB, slab_floats * sizeof(float));
+    float* ss = (float*)ws_get(WS_MISC, (size_t)2 * T * ssn * sizeof(float));
+    float* ss_a = ss;                       // sums of squares of x entering an attention block
+    float* ss_b = ss + (size_t)T * ssn;     // ... entering an MLP block
     float* d_logits = (float*)ws_get(WS_LOGITS, (size_t)B * V * sizeof(float));
     int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
 
-    launch_embed(s->x, m->embed, st.d_tokens, T, D);  // model.c:352-355
+    // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
+    launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D);
 
-    int pending = 0;  // split count of the residual-branch projection not yet added to x
     for (int l = 0; l < p->n_layers; l++) {
         const LayerPriv& lp = m->layers[l];
-        // x += previous w_down output; xb = rmsnorm(x) * rms_att          (model.c:393,361)
-        launch_rmsnorm_a16(a16_x, s->x, lp.rms_att, pending ? slab : nullptr, pending, Tpad, T, D, eps, nullptr, PC_RMSNORM);
-        // q,k,v = xb . [wq;wk;wv]^T                                        (model.c:363-365)
+        // q,k,v = rmsnorm(x) . [wq;wk;wv]^T, RoPE, K/V rows into the pool      (model.c:361-377)
         WeightEntry wqkv{lp.qkv, QD + 2 * KD, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
-        GemmEpilogue e_slab;
-        e_slab.kind = GemmEpilogue::SLAB;
-        e_slab.out = slab;
-        const int k1 = launch_gemm(wqkv, lp.qkv, QD + 2 * KD, a16_x, T, e_slab, ks_qkv, PC_GEMM_QKV);
-        // RoPE on q,k; K/V rows into the pool                              (model.c:368-377)
-        launch_rope_kv(s->q, nullptr, nullptr, slab, k1, Tpad, T, H, KVH, hd, st.d_pos, st.d_seq, st.d_tbl_off,
-                       st.d_tables, rope, pool, l, st.write_limit);
-        // attention over the block table -> fp16 hi/lo tiles               (model.c:380-383)
+        GemmEpilogue e1;
+        e1.kind = GemmEpilogue::ROPE_KV;
+        e1.ss_in = ss_a; e1.ss_tiles = ssn; e1.d_in = D; e1.eps = eps;
+        e1.q_out = s->q; e1.QD = QD; e1.KD = KD; e1.hd = hd;
+        e1.pos = st.d_pos; e1.seq = st.d_seq; e1.tbl_off = st.d_tbl_off; e1.tables = st.d_tables;
+        e1.rope = rope;
+        e1.pool_k = pool.k; e1.pool_v = pool.v; e1.kv_elem_bytes = pool.elem_bytes; e1.bs = pool.block_size;
+        e1.layer_off = (long)l * pool.layer_stride;
+        e1.write_limit = st.write_limit;
+        launch_gemm(wqkv, lp.qkv, QD + 2 * KD, a16_x, T, e1, 0, PC_GEMM_QKV);
+        // attention over the block table -> fp16 hi/lo tiles                     (model.c:380-383)
         AttnArgs at{};
         at.q = s->q;
         at.out_a16 = a16_att;
@@ -342,28 +338,47 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         at.n_runs = st.n_runs;
         at.kv_positions = st.kv_positions;
         launch_paged_attention(at);
-        // wo projection; its slabs are folded into x by the next norm      (model.c:385-388)
+        // x += att . wo^T; a16_x = x * rms_ffn; ss_b                              (model.c:385-388)
         WeightEntry wwo{lp.wo, D, QD, QD / 32, (long)(QD / 32) * TILE_HALVES, nullptr};
-        const int k2 = launch_gemm(wwo, lp.wo, D, a16_att, T, e_slab, ks_wo, PC_GEMM_WO);
-        launch_rmsnorm_a16(a16_x, s->x, lp.rms_ffn, slab, k2, Tpad, T, D, eps, nullptr, PC_RMSNORM);
-        // hb = silu(xb.w_gate^T) * (xb.w_up^T), fused in the epilogue      (model.c:389-391)
+        GemmEpilogue e2;
+        e2.kind = GemmEpilogue::RESID_A16;
+        e2.x = s->x; e2.gain_next = lp.rms_ffn; e2.a16_out = a16_x; e2.ss_out = ss_b;
+        launch_gemm(wwo, lp.wo, D, a16_att, T, e2, 0, PC_GEMM_WO);
+        // hb = silu(rmsnorm(x).w_gate^T) * (rmsnorm(x).w_up^T)                    (model.c:388-391)
         WeightEntry wgu{lp.gateup, 2 * F, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
-        GemmEpilogue e_sw;
-        e_sw.kind = GemmEpilogue::SWIGLU_A16;
-        e_sw.a16_out = a16_h;
-        launch_gemm(wgu, lp.gateup, 2 * F, a16_x, T, e_sw, 1, PC_GEMM_GATEUP);
-        // w_down projection; folded into x by the next layer's norm        (model.c:392-393)
+        GemmEpilogue e3;
+        e3.kind = GemmEpilogue::SWIGLU_A16;
+        e3.ss_in = ss_b; e3.ss_tiles = ssn; e3.d_in = D; e3.eps = eps;
+        e3.a16_out = a16_h;
+        launch_gemm(wgu, lp.gateup, 2 * F, a16_x, T, e3, 0, PC_GEMM_GATEUP);
+        // x += hb . w_down^T; a16_x = x * (next norm's gain); ss_a                (model.c:392-393,361|396)
         WeightEntry wdn{lp.down, D, F, F / 32, (long)(F / 32) * TILE_HALVES, nullptr};
-        pending = launch_gemm(wdn, lp.down, D, a16_h, T, e_slab, ks_dn, PC_GEMM_DOWN);
+        GemmEpilogue e4;
+        e4.kind = GemmEpilogue::RESID_A16;
+        e4.x = s->x;
+        e4.gain_next = l + 1 < p->n_layers ? m->layers[l + 1].rms_att : m->rms_final;
+        e4.a16_out = a16_x; e4.ss_out = ss_a;
+        launch_gemm(wdn, lp.down, D, a16_h, T, e4, 0, PC_GEMM_DOWN);
     }
-    // final norm only on the rows that produce logits, gathered            (model.c:396,411-414)
-    launch_rmsnorm_a16(a16_x, s->x, m->rms_final, pending ? slab : nullptr, pending, Tpad, B, D, eps, st.d_out_idx, PC_RMSNORM);
+    // logits only for the rows named by output_indices                            (model.c:396,411-418)
+    bool identity = B == T;
+    for (int k = 0; identity && k < B; k++) identity = output_indices[k] == k;
+    const __half* a16_head = a16_x;
+    const float* ss_head = ss_a;
+    if (!identity) {
+        __half* g16 = (__half*)ws_get(WS_A16_ATT, a16_halves(B > T ? B : T, QD > D ? QD : D) * sizeof(__half));
+        float* gss = (float*)ws_get(WS_MISC2, (size_t)B * ssn * sizeof(float));
+        launch_gather_a16(g16, gss, a16_x, ss_a, st.d_out_idx, B, D, ssn);
+        a16_head = g16;
+        ss_head = gss;
+    }
     WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
-    GemmEpilogue e_f32;
-    e_f32.kind = GemmEpilogue::F32;
-    e_f32.out = d_logits;
-    e_f32.ldo = V;
-    launch_gemm(wh, m->head, V, a16_x, B, e_f32, 1, PC_GEMM_HEAD);   // model.c:418
+    GemmEpilogue e5;
+    e5.kind = GemmEpilogue::F32;
+    e5.ss_in = ss_head; e5.ss_tiles = ssn; e5.d_in = D; e5.eps = eps;
+    e5.out = d_logits;
+    e5.ldo = V;
+    launch_gemm(wh, m->head, V, a16_head, B, e5, 1, PC_GEMM_HEAD);
     launch_argmax(d_argmax, d_logits, B, V);
 
     if (B > g_argmax_cap) {

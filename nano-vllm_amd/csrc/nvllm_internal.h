@@ -137,16 +137,49 @@ struct ProfScope {  // brackets launches on rt().stream with an event pair when 
 };
 
 // ----------------------------------------------------- kernel launchers (device ptrs)
+// What a projection does with its complete sums (see gemm.hip).
 struct GemmEpilogue {
-    enum Kind { F32 = 0, SLAB = 1, SWIGLU_A16 = 2 } kind = F32;
-    float* out = nullptr;      // F32: [T, ldo]; SLAB: [ksplit][Tpad][N]
+    enum Kind { F32 = 0, SWIGLU_A16 = 1, RESID_A16 = 2, ROPE_KV = 3 } kind = F32;
+    // Input normalisation.  When ss_in is set the activations fed to the projection are
+    // x * gain (not yet divided by the RMS) and the result is scaled per token by
+    // 1/sqrt(sum_j ss_in[t, j] / d_in + eps); ss_gather (optional) maps the projection's
+    // token index to the row of ss_in.
+    const float* ss_in = nullptr;
+    const int* ss_gather = nullptr;
+    int ss_tiles = 0;
+    int d_in = 1;
+    float eps = 0.f;
+    // F32: out[t, ldo]
+    float* out = nullptr;
     int ldo = 0;
-    __half* a16_out = nullptr; // SWIGLU_A16: tiles of [T, N/2]
+    // SWIGLU_A16 / RESID_A16: fp16 hi/lo tiles for the next projection
+    __half* a16_out = nullptr;
+    int Kb_out = 0;
+    // RESID_A16: x[t, n] += result; a16_out = x * gain_next; ss_out[t, tile] = sum over the tile of x^2
+    float* x = nullptr;
+    const float* gain_next = nullptr;
+    float* ss_out = nullptr;
+    // ROPE_KV: rows [0,QD) = q, [QD,QD+KD) = k, rest = v
+    float* q_out = nullptr;
+    int QD = 0, KD = 0, hd = 0;
+    const int* pos = nullptr;
+    const int* seq = nullptr;
+    const int* tbl_off = nullptr;
+    const int* tables = nullptr;
+    const float2* rope = nullptr;
+    void* pool_k = nullptr;
+    void* pool_v = nullptr;
+    int kv_elem_bytes = 4;
+    int bs = 16;
+    long layer_off = 0;
+    int write_limit = 0;
 };
-// out = A16[T, K] x W[N, K]^T.  Returns the k-split it used (1 unless SLAB).
+// out = A16[T, K] x W[N, K]^T followed by the epilogue.  Returns the K-split used.
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
                 const GemmEpilogue& epi, int force_ksplit, int prof_cls);
 int gemm_pick_ksplit(int N, int K, int T);
+int gemm_feature_tiles(int N);   // 64-feature tiles of a projection output = columns of ss_out
+void gemm_release();
 
 void launch_pack_a16(__half* a16, const float* in, int T, int K);
 void launch_slab_reduce(float* out, const float* slabs, int ksplit, int T, int Tpad, int N,
@@ -200,6 +233,12 @@ void launch_paged_attention(const AttnArgs& a);
 int attn_tokens_per_item(int H, int KVH);
 
 void launch_embed(float* x, const __half* table, const int* tokens, int T, int D);
+// x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 64j..64j+63
+void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
+                           const float* gain, int T, int D);
+// rows idx[r] of an a16 activation (and of its ss table) compacted to rows r = 0..B-1
+void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const float* src_ss, const int* idx,
+                       int B, int K, int ss_tiles);
 void launch_swiglu(float* out, const float* g, const float* u, long n);
 void launch_accum(float* a, const float* b, long n);
 void launch_softmax(float* x, int n);

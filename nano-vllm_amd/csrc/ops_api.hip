@@ -149,22 +149,11 @@ void matmul(float* out, float* in, float* weight, int num_tokens, int in_dim, in
         NVLLM_FATAL("matmul: handle is [%d, %d] but the call says [%d, %d]", w->N, w->K, out_dim, in_dim);
     __half* a16 = (__half*)ws_get(WS_MISC, a16_halves(num_tokens, in_dim) * sizeof(__half));
     launch_pack_a16(a16, in, num_tokens, in_dim);
-    const int ks = gemm_pick_ksplit(out_dim, in_dim, num_tokens);
-    if (ks == 1) {
-        GemmEpilogue e;
-        e.kind = GemmEpilogue::F32;
-        e.out = out;
-        e.ldo = out_dim;
-        launch_gemm(*w, w->tiles, out_dim, a16, num_tokens, e, 1, PC_GEMM_OTHER);
-    } else {
-        const int Tpad = cdiv(num_tokens, 16) * 16;
-        float* slab = (float*)ws_get(WS_MISC2, (size_t)ks * Tpad * out_dim * sizeof(float));
-        GemmEpilogue e;
-        e.kind = GemmEpilogue::SLAB;
-        e.out = slab;
-        const int used = launch_gemm(*w, w->tiles, out_dim, a16, num_tokens, e, ks, PC_GEMM_OTHER);
-        launch_slab_reduce(out, slab, used, num_tokens, Tpad, out_dim, nullptr);
-    }
+    GemmEpilogue e;
+    e.kind = GemmEpilogue::F32;
+    e.out = out;
+    e.ldo = out_dim;
+    launch_gemm(*w, w->tiles, out_dim, a16, num_tokens, e, 0, PC_GEMM_OTHER);
 }
 
 void apply_rope(float* q, float* k, int pos, float theta, int head_dim, int num_tokens, int n_heads,

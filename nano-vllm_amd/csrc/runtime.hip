@@ -331,6 +331,7 @@ void free_ops(void) {
     }
     for (auto& t : g_rope) HIP_CHECK(hipFree(t.dev));
     g_rope.clear();
+    gemm_release();
     // the stream, staging ring and weight registry stay: free_kv_cache_manager and
     // free_run_state may still be called after free_ops (reference main.c:455-469)
 }

@@ -63,3 +63,38 @@ def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
         hip.nvllm_set_logits_mode(0)
     for x, y in zip(a["histories"], b["histories"]):
         np.testing.assert_array_equal(x, y)
+
+
+def test_matmul_accepts_load_model_handles(hip, oracle, tmp_models):
+    """ops.h matmul with the `weight` pointers that load_model hands out (fp16 tiles
+    in HBM, incl. the interleaved gate/up storage) against the oracle's fp32 tensors."""
+    import ctypes as C
+    path, shape = tmp_models("tiny")
+    r = np.random.Generator(np.random.PCG64(3))
+    res = {}
+    for lib in (oracle, hip):
+        w, cfg = capi.Weights(), capi.Config()
+        lib.load_model(C.byref(w), C.byref(cfg), path.encode())
+        D, F, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+        QD, KD = cfg.n_heads * cfg.head_dim, cfg.n_kv_heads * cfg.head_dim
+        lw = w.layers[1]
+        cases = [("wq", lw.wq, D, QD), ("wk", lw.wk, D, KD), ("wv", lw.wv, D, KD), ("wo", lw.wo, QD, D),
+                 ("w_gate", lw.w_gate, D, F), ("w_up", lw.w_up, D, F), ("w_down", lw.w_down, F, D),
+                 ("lm_head", w.lm_head, D, V)]
+        out = {}
+        for T in (1, 5, 40, 70):
+            rr = np.random.Generator(np.random.PCG64(100 + T))
+            for name, handle, K, N in cases:
+                x = rr.standard_normal((T, K)).astype(np.float32)
+                dx, do = lib.to_device(x), lib.empty_device(T * N * 4)
+                lib.matmul(do, dx, handle, T, K, N)
+                out[(name, T)] = lib.to_host(do, (T, N))
+                lib.free(dx)
+                lib.free(do)
+        res[lib.kind] = out
+        if lib.kind == "hip":
+            lib.nvllm_free_model(C.byref(w))
+    for key, want in res["oracle"].items():
+        got = res["hip"][key]
+        # fp16 weights are exact in both; the activation enters as hi+lo fp16 (~2^-22 relative)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * np.abs(want).max() + 1e-7, err_msg=str(key))
