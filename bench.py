@@ -236,7 +236,8 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--max-seq-len", type=int, default=2048)
-    ap.add_argument("--kv-bytes", type=int, default=4, choices=(2, 4))
+    ap.add_argument("--kv-bytes", type=int, default=2, choices=(2, 4),
+                    help="KV pool element size: 2 = fp16 pages (default; parity covered by the fp16-pool GPU tests), 4 = the reference's fp32 rows")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2, help="0 disables the CPU baseline leg")

@@ -39,8 +39,14 @@ int  nvllm_get_logits_mode(void);
 const int* nvllm_last_argmax(int* num_outputs);
 
 /* Element type of the KV pool that init_kv_cache_manager allocates next:
- * 4 = fp32 (reference layout, bit-exact copies), 2 = fp16 (half the bytes,
- * values rounded to nearest-even on write). */
+ * 4 = fp32 (the reference's row layout, src/memory.c:37-43, bit-exact copies);
+ * 2 = fp16 (half the bytes; values rounded to nearest-even and saturated to the
+ *     finite fp16 range on write).  An fp16 pool keeps the [layer][block]
+ *     addressing -- block ids, block tables and the allocator are unchanged -- but
+ *     stores, inside a block, one 16-position page per kv head in matrix-core
+ *     operand order; it needs block_size 16 and head_dim % 16 == 0 and is opaque to
+ *     the caller (the pool pointers are never dereferenced by the reference's
+ *     driver either). */
 void nvllm_set_kv_elem_bytes(int bytes);
 int  nvllm_get_kv_elem_bytes(void);
 

@@ -34,12 +34,8 @@ struct AttnKArgs {
     long layer_off;   // elements
     long rowstride;   // elements between consecutive positions of a page (KVH * hd)
     int page;         // positions per page as seen by the kernel (16)
-    const int* pos;
-    int pos0;
-    const int* seq;
-    const int* tbl_off;
     const int* tables;
-    const int2* runs; // (first token, token count) per item
+    const int4* runs; // (first token, token count, last position, block-table offset) per item
     int n_runs;
     int H, KVH, GT, CT;
     int NG, group, gt_shift;
@@ -111,8 +107,8 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
     const int hg = (int)(widx % NG);
     const unsigned rest = widx / NG;
     const int split = (int)(rest % (unsigned)a.nsplit);
-    const int2 run = a.runs[rest / (unsigned)a.nsplit];
-    const int t0 = run.x, ntok = run.y;
+    const int4 run = a.runs[rest / (unsigned)a.nsplit];
+    const int t0 = run.x, ntok = run.y, plast = run.z;   // positions rise by one within a run
     const int h0 = hg * a.GT;
     const int kvh = (int)((unsigned)h0 / (unsigned)a.group);
 
@@ -121,15 +117,12 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
     const int ctok = x >> a.gt_shift, chead = x & (a.GT - 1);   // GT is a power of two
     const bool cvalid = ctok < ntok;
     const int tcol = t0 + (cvalid ? ctok : 0);
-    const int pcol = a.pos ? a.pos[tcol] : a.pos0 + tcol;
-    const int plim = cvalid ? pcol : -1;   // last key this column may see (none for padding columns)
-    const int tlast = t0 + ntok - 1;
-    const int plast = a.pos ? a.pos[tlast] : a.pos0 + tlast;   // positions rise within a run
-    const int npages = (plast >> 4) + 1;   // 16 == 16
+    const int plim = cvalid ? plast - (ntok - 1 - ctok) : -1;   // last key this column may see (none for padding)
+    const int npages = (plast >> 4) + 1;
     const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
     const int pg_begin = split * per;
     const int pg_end = min(npages, pg_begin + per);
-    const int* table = a.tables ? a.tables + (a.seq ? a.tbl_off[a.seq[t0]] : 0) : nullptr;
+    const int* table = a.tables ? a.tables + run.w : nullptr;
     const KVT* pk = reinterpret_cast<const KVT*>(a.pool_k) + a.layer_off + (size_t)kvh * HD;
     const KVT* pv = reinterpret_cast<const KVT*>(a.pool_v) + a.layer_off + (size_t)kvh * HD;
 
@@ -285,6 +278,202 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- fp16 pool
+// Same work decomposition for a pool in page order (see kv16_page): a page of one
+// kv head is 32*HD contiguous bytes per pool, already in v_mfma_f32_16x16x16_f16
+// operand order, so per page the wave issues 2*HD/16 contiguous 512-byte loads and
+// HD/4 fp16 MFMAs and converts nothing:
+//   S^T[key, col] = K[key, :] . Q[col, :]       A = K page, B = Q (fp16 hi + lo: two MFMAs)
+//       -> lane (col = l&15, g = l>>4) holds keys 4g..4g+3 of its column, as above;
+//   O[col, dim]  += P[col, key] V[key, dim]     A = P (those registers, fp16 hi + lo),
+//                                               B = V page
+//       -> lane (dim = 16n + (l&15), g) holds columns 4g..4g+3.
+// fp16 products are exact in the fp32 accumulator and hi + lo carries 22 bits, so the
+// arithmetic stays at fp32 accuracy.  Scores are kept in the log2 domain (one
+// v_exp_f32 per probability).  Pages beyond the slice are requested through a
+// zero-length buffer descriptor: the hardware returns zeros without touching memory,
+// so the prefetch ring needs no branches and no clamped re-reads.
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h4_t as_h4(u2_t v) { return __builtin_bit_cast(h4_t, v); }
+
+template <int HD, int PF>
+__global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
+    constexpr int NC = HD / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned NG = (unsigned)a.NG;
+    const unsigned widx = blockIdx.x * 4u + (unsigned)wave;
+    if (widx >= (unsigned)a.n_runs * NG * (unsigned)a.nsplit) return;
+    const int hg = (int)(widx % NG);
+    const unsigned rest = widx / NG;
+    const int split = (int)(rest % (unsigned)a.nsplit);
+    const int4 run = a.runs[rest / (unsigned)a.nsplit];
+    const int t0 = run.x, ntok = run.y, plast = run.z;
+    const int h0 = hg * a.GT;
+    const int kvh = (int)((unsigned)h0 / (unsigned)a.group);
+
+    const int x = lane & 15, g = lane >> 4;
+    const int ctok = x >> a.gt_shift, chead = x & (a.GT - 1);
+    const bool cvalid = ctok < ntok;
+    const int tcol = t0 + (cvalid ? ctok : 0);
+    const int plim = cvalid ? plast - (ntok - 1 - ctok) : -1;
+    const int npages = (plast >> 4) + 1;
+    const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
+    const int pg_begin = split * per;
+    const int pg_end = min(npages, pg_begin + per);
+    const int* table = a.tables + run.w;
+    const __half* pk = reinterpret_cast<const __half*>(a.pool_k) + a.layer_off;
+    const __half* pv = reinterpret_cast<const __half*>(a.pool_v) + a.layer_off;
+
+    // Q as the B operand: lane (col = x, dims 16c + 4g .. +3), split into fp16 hi + lo
+    h4_t qh[NC], ql[NC];
+    {
+        const float* qr = a.q + ((size_t)tcol * a.H + h0 + chead) * HD + 4 * g;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float4 f = cvalid ? ld4(qr + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float cl = fminf(fmaxf(fv[e], -65504.f), 65504.f);
+                qh[c][e] = (_Float16)cl;
+                ql[c][e] = (_Float16)(cl - (float)qh[c][e]);
+            }
+        }
+    }
+    const float sl2 = a.scale * 1.44269504088896340736f;   // scores in the log2 domain
+
+    float m = -INFINITY, lsum = 0.f;
+    f4_t oacc[NC];
+#pragma unroll
+    for (int n = 0; n < NC; n++) oacc[n] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    u2_t kr[PF][NC], vr[PF][NC];
+    const int voff = lane * 8;
+    auto issue = [&](int slot, int pg) {
+        const bool ok = pg < pg_end;   // wave-uniform
+        const long block = table[ok ? pg : pg_begin];
+        const long off = kv16_page(block, kvh, a.KVH, HD);
+        const int bytes = ok ? 32 * HD : 0;
+        auto rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pk + off), 0, bytes, 0x00020000);
+        auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pv + off), 0, bytes, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < NC; c++) kr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rk, voff + 512 * c, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; c++) vr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rv, voff + 512 * c, 0, 0);
+    };
+
+    auto compute = [&](int slot, int pg) {
+        // ---- scores: independent accumulator chains for the hi and lo halves of Q
+        f4_t s0 = f4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c]), qh[c], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c]), ql[c], s1, 0, 0, 0);
+            if (c + 1 < NC) {
+                s2 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c + 1]), qh[c + 1], s2, 0, 0, 0);
+                s3 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c + 1]), ql[c + 1], s3, 0, 0, 0);
+            }
+        }
+        float sc[4];
+        float mx = -INFINITY;
+        const int kfirst = pg * 16 + 4 * g;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const float v = ((s0[rr] + s2[rr]) + (s1[rr] + s3[rr])) * sl2;
+            sc[rr] = (kfirst + rr <= plim) ? v : -INFINITY;
+            mx = fmaxf(mx, sc[rr]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx > m)) {   // some column's running maximum rises (rare after the first pages)
+            const float mn = fmaxf(m, mx);
+            const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m - mn);
+            lsum *= alpha;
+            m = mn;
+            // the accumulators hold columns 4g..4g+3: fetch their factors from lanes 4g+r
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const float ar = __shfl(alpha, 4 * g + rr, 64);
+#pragma unroll
+                for (int n = 0; n < NC; n++) oacc[n][rr] *= ar;
+            }
+        }
+        const float msafe = fmaxf(m, -1.0e30f);   // nothing visible yet: exp2(-inf - finite) = 0, no NaN
+        h4_t ph, pl;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const float p = __builtin_amdgcn_exp2f(sc[rr] - msafe);
+            lsum += p;
+            ph[rr] = (_Float16)p;
+            pl[rr] = (_Float16)(p - (float)ph[rr]);
+        }
+        // ---- O += P V
+#pragma unroll
+        for (int n = 0; n < NC; n++)
+            oacc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, as_h4(vr[slot][n]), oacc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NC; n++)
+            oacc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, as_h4(vr[slot][n]), oacc[n], 0, 0, 0);
+    };
+
+    // ---- page loop: PF pages in flight per wave
+#pragma unroll
+    for (int s = 0; s < PF; s++) {
+        issue(s, pg_begin + s);
+        __builtin_amdgcn_sched_barrier(0);   // keep issue order = consumption order (counted vmcnt waits)
+    }
+    for (int pg = pg_begin; pg < pg_end; pg += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; s++) {
+            if (pg + s < pg_end) compute(s, pg + s);
+            issue(s, pg + s + PF);
+        }
+    }
+
+    // ---- results
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (a.nsplit > 1 && g == 0 && cvalid) {
+        float* pm = a.part_ml + (((size_t)tcol * a.H + h0 + chead) * a.nsplit + split) * 2;
+        pm[0] = m * 0.69314718055994530942f;   // back to the natural-log domain of k_attn_combine
+        pm[1] = lsum;
+    }
+    const float inv = 1.0f / lsum;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int col = 4 * g + rr;
+        const float invr = __shfl(inv, col, 64);
+        const int ct = col >> a.gt_shift, ch = col & (a.GT - 1);
+        if (ct >= ntok) continue;
+        const int t = t0 + ct, h = h0 + ch;
+        if (a.nsplit > 1) {
+            float* pa = a.part_acc + (((size_t)t * a.H + h) * a.nsplit + split) * HD + x;
+#pragma unroll
+            for (int n = 0; n < NC; n++) pa[16 * n] = oacc[n][rr];
+            continue;
+        }
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const float o = oacc[n][rr] * invr;
+            const int d = 16 * n + x;
+            if (a.out_f32) a.out_f32[((size_t)t * a.H + h) * HD + d] = o;
+            if (a.out_a16) {
+                const int kk = h * HD + d;
+                const float xv = fminf(fmaxf(o, -65504.f), 65504.f);
+                const __half hi = __float2half_rn(xv);
+                const __half lo = __float2half_rn(xv - __half2float(hi));
+                const size_t tl = ((size_t)(t >> 4) * a.Kb_out + (kk >> 5)) * 2;
+                const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8 + (kk & 7);
+                a.out_a16[tl * TILE_HALVES + off] = hi;
+                a.out_a16[(tl + 1) * TILE_HALVES + off] = lo;
+            }
+        }
+    }
+}
+
 // Merge the key-slice partials of each (token, head): thread = 8 consecutive dims.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_acc,
                                                       const float* __restrict__ part_ml, int T, int H, int HD,
@@ -342,7 +531,15 @@ static void launch_hd(const AttnKArgs& k, long waves, int elem_bytes) {
     if (elem_bytes == 4)
         hipLaunchKernelGGL((k_paged_attn<HD, float>), grid, block, 0, rt().stream, k);
     else
-        hipLaunchKernelGGL((k_paged_attn<HD, __half>), grid, block, 0, rt().stream, k);
+    {
+        static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 4;
+        if (HD <= 64 && pf == 8)
+            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, rt().stream, k);
+        else if (HD <= 64 && pf == 6)
+            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 6 : 2)>), grid, block, 0, rt().stream, k);
+        else
+            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 4 : 2)>), grid, block, 0, rt().stream, k);
+    }
 }
 
 extern "C" float nvllm_host_attn_scale(int head_dim);
@@ -362,9 +559,15 @@ void launch_paged_attention(const AttnArgs& a) {
     // addressed position by position through a page size of 1 ... not supported.
     if (a.tables && a.pool.block_size != 16)
         NVLLM_FATAL("paged attention supports block_size 16 (the driver's value), got %d", a.pool.block_size);
+    if (a.pool.elem_bytes == 2 && !a.tables) NVLLM_FATAL("an fp16 KV pool is always paged");
     const long base_items = (long)a.n_runs * NG;
     const int pages = (a.max_pos + 16) / 16;
-    static const int target_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 2048;
+    // Work items are cut into key slices until about this many waves exist.  The fp32
+    // kernel is bound by its own instruction stream and wants 2 waves per SIMD; the
+    // fp16 kernel is bound by memory and by per-wave fixed costs (descriptor, Q,
+    // partials) and is fastest with 3 waves per CU, 4 pages in flight each.
+    static const int env_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 0;
+    const int target_waves = env_waves > 0 ? env_waves : (a.pool.elem_bytes == 2 ? 768 : 2048);
     int nsplit = (int)((target_waves + base_items - 1) / base_items);
     if (nsplit > (pages + 1) / 2) nsplit = (pages + 1) / 2;   // at least two pages per slice
     if (nsplit < 1) nsplit = 1;
@@ -377,12 +580,8 @@ void launch_paged_attention(const AttnArgs& a) {
     k.layer_off = (long)a.layer * a.pool.layer_stride;
     k.rowstride = (long)a.KVH * a.hd;
     k.page = 16;
-    k.pos = a.pos;
-    k.pos0 = a.pos0;
-    k.seq = a.seq;
-    k.tbl_off = a.tbl_off;
     k.tables = a.tables;
-    k.runs = (const int2*)a.runs;
+    k.runs = (const int4*)a.runs;
     k.n_runs = a.n_runs;
     k.H = a.H;
     k.KVH = a.KVH;

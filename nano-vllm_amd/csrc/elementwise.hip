@@ -369,97 +369,49 @@ template <>
 __device__ __forceinline__ void kv_store2<__half>(__half* dst, float a, float b) {
     *reinterpret_cast<__half2*>(dst) = __halves2half2(__float2half_rn(a), __float2half_rn(b));
 }
-
-// Fused: q,k,v = sum of the projection's split-K slabs; rotate q and k; store q as
-// fp32 rows and scatter k,v into the block pool (reference model.c:363-377).
 template <typename KVT>
-__global__ __launch_bounds__(256) void k_rope_kv(float* __restrict__ q_out, float* __restrict__ k_out,
-                                                 float* __restrict__ v_out,
-                                                 const float* __restrict__ slabs, int ksplit,
-                                                 long slab_stride, int H, int KVH, int hd,
-                                                 const int* __restrict__ pos, const int* __restrict__ seq,
-                                                 const int* __restrict__ tbl_off,
-                                                 const int* __restrict__ tables,
-                                                 const float2* __restrict__ rope, KVT* pool_k, KVT* pool_v,
-                                                 int bs, long layer_off, int write_limit) {
-    const int t = blockIdx.x;
-    const int p = pos[t];
-    const int half = hd >> 1;
-    const int QD = H * hd, KD = KVH * hd, ND = QD + 2 * KD;
-    const float2* tab = rope + (size_t)p * half;
-    const float* src = slabs + (size_t)t * ND;
-    const int* table = tables + tbl_off[seq[t]];
-    const bool store_kv = t < write_limit;
-    const long row = store_kv ? kv_row(table, p, bs) : 0;
-    KVT* kd = pool_k + layer_off + row * KD;
-    KVT* vd = pool_v + layer_off + row * KD;
-    for (int i = threadIdx.x; i < ND / 2; i += blockDim.x) {
-        float2 v = reinterpret_cast<const float2*>(src)[i];
-        for (int s0 = 1; s0 < ksplit; s0 += 8) {  // loads first, adds after (see k_rmsnorm)
-            float2 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (s0 + u < ksplit) w[u] = reinterpret_cast<const float2*>(src + (s0 + u) * slab_stride)[i];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (s0 + u < ksplit) { v.x += w[u].x; v.y += w[u].y; }
-        }
-        const int e = 2 * i;
-        if (e < QD) {
-            const float2 r = rot(v.x, v.y, tab[i % half]);
-            reinterpret_cast<float2*>(q_out + (size_t)t * QD)[i] = r;
-        } else if (e < QD + KD) {
-            const int j = i - QD / 2;
-            const float2 r = rot(v.x, v.y, tab[j % half]);
-            if (k_out) reinterpret_cast<float2*>(k_out + (size_t)t * KD)[j] = r;
-            if (store_kv) kv_store2<KVT>(kd + 2 * j, r.x, r.y);
-        } else {
-            const int j = i - (QD + KD) / 2;
-            if (v_out) reinterpret_cast<float2*>(v_out + (size_t)t * KD)[j] = v;
-            if (store_kv) kv_store2<KVT>(vd + 2 * j, v.x, v.y);
-        }
-    }
+__device__ __forceinline__ void kv_store1(KVT* dst, float a);
+template <>
+__device__ __forceinline__ void kv_store1<float>(float* dst, float a) { *dst = a; }
+template <>
+__device__ __forceinline__ void kv_store1<__half>(__half* dst, float a) {   // finite fp16 only
+    *dst = __float2half_rn(fminf(fmaxf(a, -65504.f), 65504.f));
 }
 
-void launch_rope_kv(float* q, float* k, float* v, const float* slabs, int ksplit, int Tpad, int T, int H,
-                    int KVH, int hd, const int* pos, const int* seq, const int* tbl_off, const int* tables,
-                    const float2* rope, const KvPoolView& pool, int layer, int write_limit) {
-    if (T <= 0) return;
-    const int ND = (H + 2 * KVH) * hd;
-    ProfScope ps(PC_ROPE_KV, (double)T * ND * 4.0 * (ksplit + 1), 0);
-    const long slab_stride = (long)Tpad * ND;
-    const long layer_off = (long)layer * pool.layer_stride;
-    if (pool.elem_bytes == 4)
-        hipLaunchKernelGGL(k_rope_kv<float>, dim3(T), dim3(256), 0, rt().stream, q, k, v, slabs, ksplit,
-                           slab_stride, H, KVH, hd, pos, seq, tbl_off, tables, rope, (float*)pool.k,
-                           (float*)pool.v, pool.block_size, layer_off, write_limit);
-    else
-        hipLaunchKernelGGL(k_rope_kv<__half>, dim3(T), dim3(256), 0, rt().stream, q, k, v, slabs, ksplit,
-                           slab_stride, H, KVH, hd, pos, seq, tbl_off, tables, rope, (__half*)pool.k,
-                           (__half*)pool.v, pool.block_size, layer_off, write_limit);
-}
-
-// Plain scatter of K/V rows (reference attention.c:11-30, :109-175).
+// Plain scatter of K/V rows (reference attention.c:11-30, :109-175).  fp32 pools
+// keep the reference's rows; fp16 pools are in page order (see kv16_page).
 template <typename KVT>
 __global__ __launch_bounds__(256) void k_kv_write(const float* __restrict__ k, const float* __restrict__ v,
                                                   const int* __restrict__ pos, int pos0,
                                                   const int* __restrict__ seq,
                                                   const int* __restrict__ tbl_off,
                                                   const int* __restrict__ tables, KVT* pool_k, KVT* pool_v,
-                                                  int bs, long layer_off, int KD) {
+                                                  int bs, long layer_off, int KVH, int hd) {
     const int t = blockIdx.x;
     const int p = pos ? pos[t] : pos0 + t;
     const int* table = tables ? tables + (seq ? tbl_off[seq[t]] : 0) : nullptr;
-    const long row = kv_row(table, p, bs);
-    KVT* kd = pool_k + layer_off + row * KD;
-    KVT* vd = pool_v + layer_off + row * KD;
+    const int KD = KVH * hd;
     const float* ks = k + (size_t)t * KD;
     const float* vs = v + (size_t)t * KD;
-    for (int i = threadIdx.x; i < KD / 2; i += blockDim.x) {
-        const float2 a = reinterpret_cast<const float2*>(ks)[i];
-        const float2 b = reinterpret_cast<const float2*>(vs)[i];
-        kv_store2<KVT>(kd + 2 * i, a.x, a.y);
-        kv_store2<KVT>(vd + 2 * i, b.x, b.y);
+    if (sizeof(KVT) == 4) {
+        const long row = kv_row(table, p, bs);
+        KVT* kd = pool_k + layer_off + row * KD;
+        KVT* vd = pool_v + layer_off + row * KD;
+        for (int i = threadIdx.x; i < KD / 2; i += blockDim.x) {
+            const float2 a = reinterpret_cast<const float2*>(ks)[i];
+            const float2 b = reinterpret_cast<const float2*>(vs)[i];
+            kv_store2<KVT>(kd + 2 * i, a.x, a.y);
+            kv_store2<KVT>(vd + 2 * i, b.x, b.y);
+        }
+    } else {
+        const long block = table[p / KV16_PAGE_KEYS];
+        const int key = p % KV16_PAGE_KEYS;
+        for (int i = threadIdx.x; i < KD; i += blockDim.x) {
+            const int kvh = i / hd, d = i % hd;
+            const long page = layer_off + kv16_page(block, kvh, KVH, hd);
+            kv_store1<KVT>(pool_k + page + kv16_k_off(key, d), ks[i]);
+            kv_store1<KVT>(pool_v + page + kv16_v_off(key, d), vs[i]);
+        }
     }
 }
 
@@ -471,12 +423,15 @@ void launch_kv_write(const float* k, const float* v, const int* pos, int pos0, c
     if (KD % 2) NVLLM_FATAL("KV row width %d must be even", KD);
     ProfScope ps(PC_ROPE_KV, (double)T * KD * 2 * (4.0 + pool.elem_bytes), 0);
     const long layer_off = (long)layer * pool.layer_stride;
-    if (pool.elem_bytes == 4)
+    if (pool.elem_bytes == 4) {
         hipLaunchKernelGGL(k_kv_write<float>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
-                           tables, (float*)pool.k, (float*)pool.v, pool.block_size, layer_off, KD);
-    else
+                           tables, (float*)pool.k, (float*)pool.v, pool.block_size, layer_off, KVH, hd);
+    } else {
+        if (!tables || pool.block_size != KV16_PAGE_KEYS || hd % 16)
+            NVLLM_FATAL("an fp16 KV pool needs block tables, block_size 16 and head_dim %% 16 == 0");
         hipLaunchKernelGGL(k_kv_write<__half>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
-                           tables, (__half*)pool.k, (__half*)pool.v, pool.block_size, layer_off, KD);
+                           tables, (__half*)pool.k, (__half*)pool.v, pool.block_size, layer_off, KVH, hd);
+    }
 }
 
 // ------------------------------------------------------------- small ops

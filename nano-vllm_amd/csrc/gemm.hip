@@ -99,10 +99,23 @@ template <>
 __device__ __forceinline__ void kv_put4<float>(float* dst, const float* y) {
     *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
 }
+__device__ __forceinline__ __half kv_sat_half(float v) {   // finite fp16 only: masked keys need 0 * finite = 0
+    return __float2half_rn(fminf(fmaxf(v, -65504.f), 65504.f));
+}
 template <>
 __device__ __forceinline__ void kv_put4<__half>(__half* dst, const float* y) {
-    alignas(8) __half h[4] = {__float2half_rn(y[0]), __float2half_rn(y[1]), __float2half_rn(y[2]), __float2half_rn(y[3])};
+    alignas(8) __half h[4] = {kv_sat_half(y[0]), kv_sat_half(y[1]), kv_sat_half(y[2]), kv_sat_half(y[3])};
     *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(h);
+}
+// four consecutive dims of one key in a V page: 4 halves apart
+template <typename KVT>
+__device__ __forceinline__ void kv_put4_strided(KVT* dst, const float* y);
+template <>
+__device__ __forceinline__ void kv_put4_strided<float>(float*, const float*) {}
+template <>
+__device__ __forceinline__ void kv_put4_strided<__half>(__half* dst, const float* y) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) dst[4 * e] = kv_sat_half(y[e]);
 }
 
 template <int NBW, int TB, int NW, int EPI, typename KVT>
@@ -390,11 +403,19 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                         *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
                     } else if (t < ep.write_limit) {
                         const int* table = ep.tables + ep.tbl_off[ep.seq[t]];
-                        const long row = (long)table[pos / ep.bs] * ep.bs + (pos % ep.bs);
+                        const long block = table[pos / ep.bs];
+                        const int key = pos % ep.bs;
                         const bool is_k = n < ep.QD + ep.KD;
                         const int c = is_k ? n - ep.QD : n - ep.QD - ep.KD;
-                        KVT* dst = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off + row * ep.KD + c;
-                        kv_put4<KVT>(dst, y);
+                        KVT* pool = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off;
+                        if (sizeof(KVT) == 4) {   // the reference's rows (memory.c:37-43)
+                            kv_put4<KVT>(pool + (block * ep.bs + key) * ep.KD + c, y);
+                        } else {                  // fp16 pages in matrix-core operand order
+                            const int kvh = c / ep.hd, d = c % ep.hd;
+                            KVT* page = pool + kv16_page(block, kvh, ep.KD / ep.hd, ep.hd);
+                            if (is_k) kv_put4<KVT>(page + kv16_k_off(key, d), y);
+                            else kv_put4_strided<KVT>(page + kv16_v_off(key, d), y);
+                        }
                     }
                 }
             }

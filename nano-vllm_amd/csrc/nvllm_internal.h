@@ -201,11 +201,29 @@ struct KvPoolView {
     int num_blocks;
     long layer_stride; // elements
 };
-// q,k,v <- sum of slabs (if any), rotate q,k, write q (fp32) and scatter k,v rows.
-void launch_rope_kv(float* q, float* k, float* v, const float* slabs, int ksplit, int Tpad, int T,
-                    int H, int KVH, int hd, const int* pos, const int* seq, const int* tbl_off,
-                    const int* tables, const float2* rope, const KvPoolView& pool, int layer,
-                    int write_limit);
+
+// ---- fp16 pool: "page order".  The fp32 pool keeps the reference's row layout
+// [layer][block][position][kv head][dim] (memory.c:37-43).  The fp16 pool keeps the
+// same [layer][block] addressing (block ids, block tables and the allocator are
+// untouched) but inside a block it stores one PAGE per kv head -- the block's 16
+// positions x hd dims of that head -- with the elements in the register order of
+// a v_mfma_f32_16x16x16_f16 operand, so that the attention kernel reads a page as
+// hd/16 fully contiguous 512-byte wave loads per pool and feeds them to the matrix
+// cores without conversion or shuffles:
+//   K page (A operand, rows = keys):  (key, d) -> (d>>4)*256 + (((d>>2)&3)*16 + key)*4 + (d&3)
+//   V page (B operand, k = keys):     (key, d) -> (d>>4)*256 + ((key>>2)*16 + (d&15))*4 + (key&3)
+// Values are saturated to the finite fp16 range when written and fresh pools are
+// zero-filled, so every half in the pool is finite (masked keys rely on 0 * finite = 0).
+constexpr int KV16_PAGE_KEYS = 16;
+__host__ __device__ __forceinline__ long kv16_page(long block, int kvh, int KVH, int hd) {
+    return (block * KVH + kvh) * (long)(KV16_PAGE_KEYS * hd);
+}
+__host__ __device__ __forceinline__ int kv16_k_off(int key, int d) {
+    return (d >> 4) * 256 + ((((d >> 2) & 3) * 16 + key) << 2) + (d & 3);
+}
+__host__ __device__ __forceinline__ int kv16_v_off(int key, int d) {
+    return (d >> 4) * 256 + (((key >> 2) * 16 + (d & 15)) << 2) + (key & 3);
+}
 void launch_rope(float* q, float* k, const int* pos, int pos0, const float2* rope, int T, int H,
                  int KVH, int hd);
 void launch_kv_write(const float* k, const float* v, const int* pos, int pos0, const int* seq,
@@ -225,8 +243,8 @@ struct AttnArgs {
     const int* tables;     // device, concatenated block tables (null: contiguous cache)
     int T, H, KVH, hd;
     int max_pos;           // largest position in the batch (host knowledge, for split sizing)
-    const int* runs;       // device (first token, count) pairs: runs of consecutive positions
-    int n_runs;            //   of one sequence, at most attn_tokens_per_item() tokens each
+    const int* runs;       // device int4 (first token, count, last position, table offset): runs of consecutive
+    int n_runs;            //   positions of one sequence, at most attn_tokens_per_item() tokens each
     long kv_positions;     // sum over runs of (last position + 1): rows of K/V each kv head reads
 };
 void launch_paged_attention(const AttnArgs& a);

@@ -70,6 +70,10 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
     }
     size_t total_tbl = 0;
     for (int i = 0; i < n_seqs; i++) total_tbl += (size_t)need[i];
+    std::vector<int> tbl_off(n_seqs, 0);
+    for (int i = 1; i < n_seqs; i++) tbl_off[i] = tbl_off[i - 1] + need[i - 1];
+    // attention work items: (first token, token count, last position, offset of the
+    // sequence's block table) -- everything a wave needs in one 16-byte load
     std::vector<int> runs;
     s.kv_positions = 0;
     if (attn_ct > 0) {
@@ -80,11 +84,13 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
             while (t + n < T && n < attn_ct && seq_of(t + n) == seq_of(t) && pos_of(t + n) == pos_of(t + n - 1) + 1) n++;
             runs.push_back(t);
             runs.push_back(n);
+            runs.push_back(pos_of(t + n - 1));
+            runs.push_back(tbl_off[seq_of(t)]);
             s.kv_positions += pos_of(t + n - 1) + 1;
             t += n;
         }
     }
-    s.n_runs = (int)runs.size() / 2;
+    s.n_runs = (int)runs.size() / 4;
     const size_t n_ints = (size_t)(tokens ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) +
                           (output_indices ? B : 0) + n_seqs + total_tbl + runs.size() + 64;
     int* host = pinned_ints(n_ints);
@@ -110,7 +116,7 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
         s.d_tables = dev + o;
         size_t run = 0;
         for (int i = 0; i < n_seqs; i++) {
-            off_host[i] = (int)run;
+            off_host[i] = tbl_off[i];
             if (need[i] > 0) {
                 const BlockTable* bt = single ? single : tables[i];
                 memcpy(host + o + run, bt->block_indices, (size_t)need[i] * sizeof(int));
@@ -119,7 +125,7 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
         }
         o += run;
     }
-    o = (o + 1) & ~(size_t)1;  // int2 alignment
+    o = (o + 3) & ~(size_t)3;  // int4 alignment
     s.d_runs = runs.empty() ? nullptr : put(runs.data(), runs.size());
     if (o > 0) HIP_CHECK(hipMemcpyAsync(dev, host, o * sizeof(int), hipMemcpyHostToDevice, rt().stream));
     return s;
@@ -200,6 +206,9 @@ void init_kv_cache_manager(KVCacheManager* mgr, int block_size, int num_blocks, 
     for (int slot = 0; slot < num_blocks; slot++) mgr->free_block_indices[slot] = num_blocks - 1 - slot;
     const size_t elems = (size_t)n_layers * num_blocks * block_size * n_kv_heads * head_dim;
     const int eb = rt().kv_elem_bytes;
+    if (eb == 2 && (block_size != KV16_PAGE_KEYS || head_dim % 16 != 0))
+        NVLLM_FATAL("an fp16 KV pool stores 16-position pages: block_size must be 16 (got %d) and head_dim a "
+                    "multiple of 16 (got %d)", block_size, head_dim);
     void *pk = nullptr, *pv = nullptr;
     if (device_malloc(&pk, elems * eb) != 0 || device_malloc(&pv, elems * eb) != 0)
         NVLLM_FATAL("cannot allocate the KV pool (2 x %zu bytes)", elems * eb);

@@ -51,6 +51,23 @@ def test_stories15m_shape_greedy_256(hip, oracle, tmp_models):
     assert worst < TIGHT_TOL, worst
 
 
+def test_fp16_kv_pool_keeps_greedy_parity(hip, oracle, tmp_models):
+    """The benchmark's configuration: KV rows stored as fp16 (the reference keeps fp32).
+    Greedy tokens must stay identical over 256 steps and logits within the stated bar."""
+    path, shape = tmp_models("stories15M", max_seq_len=512)
+    prompts = synth.make_requests(3, 20, 90, shape.vocab_size, seed=11)
+    kw = dict(n_new=256, arrivals=[0, 0, 3], collect_logits=True, chunk_size=64, temperature=0.0, max_steps=2000)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare_runs(g, o)
+    assert worst < LOGITS_TOL / 10, worst
+
+
 def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
     path, shape = tmp_models("tiny")
     prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=6)

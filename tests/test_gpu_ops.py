@@ -152,6 +152,65 @@ def test_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
     po.close()
 
 
+@pytest.mark.parametrize("hd,H,KVH", [(64, 32, 4), (48, 6, 6), (128, 8, 8), (16, 4, 2), (64, 8, 1), (96, 2, 2)])
+def test_fp16_pool_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
+    """The fp16 pool (pages in matrix-core operand order).  Written rows must be the
+    fp16 roundings of what the reference stores, at the reference's logical
+    coordinates; attention over the pool must match the oracle run on those rounded
+    values to fp32 accuracy."""
+    r = rng(hd * 11 + H)
+    L, bs, S = 2, 16, 1024
+    ctx = [40, 1, 16, 17, 100, 1000, 33]
+    n_seqs, maxb = len(ctx), S // bs
+    nb = sum((c + bs - 1) // bs for c in ctx) + 5
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(4)
+    hip.nvllm_set_kv_elem_bytes(2)   # Pool helpers ask the library for the element size
+    try:
+        perm = r.permutation(nb)
+        cur = 0
+        for s, c in enumerate(ctx):
+            need = (c + bs - 1) // bs
+            blocks = perm[cur:cur + need].tolist()
+            cur += need
+            ph.set_table(s, blocks)
+            po.set_table(s, blocks)
+        h16 = lambda a: a.astype(np.float16).astype(np.float32)
+        kfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        vfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        ph.fill(kfill, vfill)
+        po.fill(kfill, vfill)
+        np.testing.assert_array_equal(ph.dump("k"), kfill)          # the helpers' view of the layout round-trips
+        pos, sid = [], []
+        for p in range(ctx[0] - 21, ctx[0]):
+            pos.append(p)
+            sid.append(0)
+        for s in range(1, n_seqs):
+            pos.append(ctx[s] - 1)
+            sid.append(s)
+        T = len(pos)
+        k = r.standard_normal((T, KVH * hd)).astype(np.float32)
+        v = r.standard_normal((T, KVH * hd)).astype(np.float32)
+        k[0, 0], v[0, 1] = 1e6, -1e6                                # saturate instead of overflowing to inf
+        q = r.standard_normal((T, H * hd)).astype(np.float32)
+        sat = lambda a: h16(np.clip(a, -65504, 65504))
+        layer = 1
+        util.op_kv_write_batch(oracle, po, sat(k), sat(v), layer, pos, sid, KVH, hd)
+        util.op_kv_write_batch(hip, ph, k, v, layer, pos, sid, KVH, hd)
+        np.testing.assert_array_equal(ph.dump("k"), po.dump("k"))
+        np.testing.assert_array_equal(ph.dump("v"), po.dump("v"))
+        want = util.op_paged_attention_batch(oracle, po, q, layer, pos, sid, S, H, KVH, hd)
+        got = util.op_paged_attention_batch(hip, ph, q, layer, pos, sid, S, H, KVH, hd)
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.abs(want).max() + 2e-6)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(4)
+        ph.close()
+        po.close()
+
+
 def test_kv_write_table_too_small_stops(hip, oracle, capfd):
     """Reference attention.c:159-162: the first token whose logical block is not in
     the table prints and ends the call; later tokens are not written."""

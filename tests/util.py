@@ -54,20 +54,51 @@ class Pool:
         L, KVH, hd = self.geom
         return L * self.mgr.num_blocks * self.mgr.block_size * KVH * hd
 
+    # ---- fp16 pools of the HIP library are stored in page order: inside a block one
+    # page per kv head, elements in matrix-core operand order (include/nvllm.h,
+    # nvllm_set_kv_elem_bytes).  These helpers translate to / from the reference's
+    # logical layout [layer][block][position][kv head][dim].
+    def _page_offsets(self, which):
+        L, KVH, hd = self.geom
+        key = np.arange(16)[:, None]
+        d = np.arange(hd)[None, :]
+        if which == "k":
+            return (d >> 4) * 256 + ((((d >> 2) & 3) * 16 + key) << 2) + (d & 3)
+        return (d >> 4) * 256 + (((key >> 2) * 16 + (d & 15)) << 2) + (key & 3)
+
+    def _is_fp16(self):
+        return self.lib.kind == "hip" and self.lib.nvllm_get_kv_elem_bytes() == 2
+
     def dump(self, which="k"):
+        """Pool contents as fp32 in the reference's logical layout."""
         p = self.mgr.pool_k if which == "k" else self.mgr.pool_v
-        eb = self.lib.nvllm_get_kv_elem_bytes() if self.lib.kind == "hip" else 4
-        dt = np.float32 if eb == 4 else np.float16
-        return self.lib.to_host(p, (self.elems(),), dt).astype(np.float32)
+        if not self._is_fp16():
+            return self.lib.to_host(p, (self.elems(),), np.float32)
+        L, KVH, hd = self.geom
+        nb, bs = self.mgr.num_blocks, self.mgr.block_size
+        assert bs == 16
+        raw = self.lib.to_host(p, (L, nb, KVH, 16 * hd), np.float16)
+        off = self._page_offsets(which)                       # [16, hd]
+        logical = raw[:, :, :, off]                           # [L, nb, KVH, 16, hd]
+        return np.ascontiguousarray(logical.transpose(0, 1, 3, 2, 4)).astype(np.float32).reshape(-1)
 
     def fill(self, k_vals, v_vals):
-        """Overwrite both pools with host data (fp32 pool only)."""
-        if self.lib.kind == "hip":
-            self.lib.device_memcpy(self.mgr.pool_k, f32(k_vals).ctypes.data, k_vals.size * 4, capi.HOST_TO_DEVICE)
-            self.lib.device_memcpy(self.mgr.pool_v, f32(v_vals).ctypes.data, v_vals.size * 4, capi.HOST_TO_DEVICE)
-        else:
+        """Overwrite both pools with host data given in the logical layout."""
+        if self.lib.kind != "hip":
             C.memmove(self.mgr.pool_k, f32(k_vals).ctypes.data, k_vals.size * 4)
             C.memmove(self.mgr.pool_v, f32(v_vals).ctypes.data, v_vals.size * 4)
+            return
+        if not self._is_fp16():
+            self.lib.device_memcpy(self.mgr.pool_k, f32(k_vals).ctypes.data, k_vals.size * 4, capi.HOST_TO_DEVICE)
+            self.lib.device_memcpy(self.mgr.pool_v, f32(v_vals).ctypes.data, v_vals.size * 4, capi.HOST_TO_DEVICE)
+            return
+        L, KVH, hd = self.geom
+        nb = self.mgr.num_blocks
+        for which, vals, dst in (("k", k_vals, self.mgr.pool_k), ("v", v_vals, self.mgr.pool_v)):
+            logical = np.asarray(vals, dtype=np.float16).reshape(L, nb, 16, KVH, hd).transpose(0, 1, 3, 2, 4)
+            raw = np.zeros((L, nb, KVH, 16 * hd), np.float16)
+            raw[:, :, :, self._page_offsets(which)] = logical
+            self.lib.device_memcpy(dst, raw.ctypes.data, raw.nbytes, capi.HOST_TO_DEVICE)
 
     def close(self):
         self.lib.free_kv_cache_manager(C.byref(self.mgr))
