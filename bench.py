@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -177,11 +178,13 @@ def run_gpu(args, env, shape, model_path):
         for _ in range(args.profile_steps):
             eng.step()
         lib.nvllm_prof_enable(0)
+        bracket_ms = lib.nvllm_prof_event_overhead_ms()   # what an empty event pair measures
         for c in range(lib.nvllm_prof_num_classes()):
             n, ms, by, fl = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
             lib.nvllm_prof_get(c, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
             if n.value:
-                prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, total_ms=ms.value,
+                prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, raw_ms=ms.value,
+                                                             total_ms=max(ms.value - n.value * bracket_ms, 1e-9),
                                                              bytes=by.value, flops=fl.value)
     hist = eng.history(0)[-4:].tolist()
     eng.close()
@@ -240,7 +243,7 @@ def main():
                     help="KV pool element size: 2 = fp16 pages (default; parity covered by the fp16-pool GPU tests), 4 = the reference's fp32 rows")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
     args = ap.parse_args()
 
@@ -257,15 +260,33 @@ def main():
     prefill_tps = env.reduce(r["prefill_tokens"] / r["prefill_s"], "SUM")
 
     if env.rank == 0:
-        roofline = None
+        roofline, by_kernel = None, {}
         if r["prof"]:
-            name, d = max(r["prof"].items(), key=lambda kv: kv[1]["total_ms"])
-            avg_ms = d["total_ms"] / d["launches"]
-            achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                            avg_kernel_us=round(avg_ms * 1e3, 2), launches=d["launches"],
-                            algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]))
+            # group the timing classes by kernel symbol: all projections are one kernel
+            sym = lambda cls: ("k_gemm" if cls.startswith("gemm") else
+                               ("k_paged_attn16" if args.kv_bytes == 2 else "k_paged_attn") if cls == "attn" else
+                               {"attn_combine": "k_attn_combine", "argmax": "k_argmax", "embed": "k_embed_prescale"}.get(cls, cls))
+            for cls, d in r["prof"].items():
+                g = by_kernel.setdefault(sym(cls), dict(launches=0, total_ms=0.0, raw_ms=0.0, bytes=0.0))
+                for k in g:
+                    g[k] += d[k]
+            pmc = {}
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
+            if os.path.exists(pmc_path) and args.model == "tinyllama-1.1b" and args.batch == 64 and args.kv_bytes == 2:
+                pmc = json.load(open(pmc_path))["kernels"]     # measured on this workload in separate --pmc passes
+            def roof(name):
+                d = by_kernel[name]
+                avg_ms = d["total_ms"] / d["launches"]
+                achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+                return dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 4),
+                            traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"),
+                            avg_kernel_us=round(avg_ms * 1e3, 2),   # event pair minus the empty-pair time
+                            avg_event_pair_us=round(d["raw_ms"] / d["launches"] * 1e3, 2), launches=d["launches"],
+                            algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
+                            share_of_step=round(d["total_ms"] / args.profile_steps / ms_per_step, 3))
+            roofline = roof(max(by_kernel, key=lambda k: by_kernel[k]["total_ms"]))   # the kernel the step spends most time in
+            by_kernel = {k: roof(k) for k in by_kernel}
         cpu = None
         if N == 1 and args.cpu_steps > 0:
             cpu = cpu_baseline(args, shape, model_path)
@@ -283,6 +304,7 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes,
                        "graph_replay": bool(args.graph)},
             "roofline": roofline,
+            "roofline_by_kernel": by_kernel,
             "cpu_baseline": cpu,
             "step_hbm": {"algorithmic_bytes_per_step": int(r["step_bytes"]), "achieved_GBps": round(step_gbs, 1),
                          "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},

@@ -65,6 +65,9 @@ const char* nvllm_prof_name(int cls);
  * (what the kernel must read+write at least once) and flops.  Resolves pending
  * events (synchronises the stream). */
 void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* bytes, double* flops);
+/* Mean elapsed time of an empty event pair on the library stream: the part of every
+ * timed launch that is the bracket, not the kernel. */
+double nvllm_prof_event_overhead_ms(void);
 
 /* ------------------------------------------------------ N-sequence driver */
 /* The reference's scheduler with the sequence count as a parameter: arrival

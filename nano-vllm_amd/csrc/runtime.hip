@@ -238,6 +238,31 @@ void nvllm_prof_reset(void) {
         g_prof_ms[i] = g_prof_bytes[i] = g_prof_flops[i] = 0.0;
     }
 }
+// Elapsed time of an event pair with nothing between the two records: what the
+// bracket itself adds to every timed launch (packet processing on either side).
+double nvllm_prof_event_overhead_ms(void) {
+    ensure_init();
+    const int n = 64;
+    hipEvent_t a[n], b[n];
+    for (int i = 0; i < n; i++) {
+        a[i] = prof_event();
+        b[i] = prof_event();
+    }
+    for (int i = 0; i < n; i++) {
+        HIP_CHECK(hipEventRecord(a[i], g_rt.stream));
+        HIP_CHECK(hipEventRecord(b[i], g_rt.stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+    double tot = 0.0;
+    for (int i = 0; i < n; i++) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a[i], b[i]));
+        tot += ms;
+        g_prof_free.push_back(a[i]);
+        g_prof_free.push_back(b[i]);
+    }
+    return tot / n;
+}
 int nvllm_prof_num_classes(void) { return PC_COUNT; }
 const char* nvllm_prof_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
 void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* bytes, double* flops) {
