@@ -303,9 +303,10 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // one WORKGROUP per (item, key slice); its four waves take the slice's pages
+    // round-robin and merge through LDS at the end
     const unsigned NG = (unsigned)a.NG;
-    const unsigned widx = blockIdx.x * 4u + (unsigned)wave;
-    if (widx >= (unsigned)a.n_runs * NG * (unsigned)a.nsplit) return;
+    const unsigned widx = blockIdx.x;
     const int hg = (int)(widx % NG);
     const unsigned rest = widx / NG;
     const int split = (int)(rest % (unsigned)a.nsplit);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     const int plim = cvalid ? plast - (ntok - 1 - ctok) : -1;
     const int npages = (plast >> 4) + 1;
     const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
-    const int pg_begin = split * per;
-    const int pg_end = min(npages, pg_begin + per);
+    const int pg_begin = split * per + wave;            // this wave: pages pg_begin, +4, +8 ...
+    const int pg_end = min(npages, split * per + per);
     const int* table = a.tables + run.w;
     const __half* pk = reinterpret_cast<const __half*>(a.pool_k) + a.layer_off;
     const __half* pv = reinterpret_cast<const __half*>(a.pool_v) + a.layer_off;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     const int voff = lane * 8;
     auto issue = [&](int slot, int pg) {
         const bool ok = pg < pg_end;   // wave-uniform
-        const long block = table[ok ? pg : pg_begin];
+        const long block = table[ok ? pg : 0];
         const long off = kv16_page(block, kvh, a.KVH, HD);
         const int bytes = ok ? 32 * HD : 0;
         auto rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pk + off), 0, bytes, 0x00020000);
@@ -422,43 +423,60 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     // ---- page loop: PF pages in flight per wave
 #pragma unroll
     for (int s = 0; s < PF; s++) {
-        issue(s, pg_begin + s);
+        issue(s, pg_begin + 4 * s);
         __builtin_amdgcn_sched_barrier(0);   // keep issue order = consumption order (counted vmcnt waits)
     }
-    for (int pg = pg_begin; pg < pg_end; pg += PF) {
+    for (int pg = pg_begin; pg < pg_end; pg += 4 * PF) {
 #pragma unroll
         for (int s = 0; s < PF; s++) {
-            if (pg + s < pg_end) compute(s, pg + s);
-            issue(s, pg + s + PF);
+            if (pg + 4 * s < pg_end) compute(s, pg + 4 * s);
+            issue(s, pg + 4 * (s + PF));
         }
     }
 
-    // ---- results
+    // ---- merge the four waves through LDS: per column (max, sum), per lane the accumulators
+    __shared__ float s_m[4][16], s_l[4][16];
+    __shared__ f4_t s_o[4][NC][64];
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
-    if (a.nsplit > 1 && g == 0 && cvalid) {
-        float* pm = a.part_ml + (((size_t)tcol * a.H + h0 + chead) * a.nsplit + split) * 2;
-        pm[0] = m * 0.69314718055994530942f;   // back to the natural-log domain of k_attn_combine
-        pm[1] = lsum;
+    if (g == 0) {
+        s_m[wave][x] = m;
+        s_l[wave][x] = lsum;
     }
-    const float inv = 1.0f / lsum;
+#pragma unroll
+    for (int n = 0; n < NC; n++) s_o[wave][n][lane] = oacc[n];
+    __syncthreads();
+    // wave w finishes dim blocks n = w, w+4, ...; lane (dim 16n + x, g) owns columns 4g..4g+3
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         const int col = 4 * g + rr;
-        const float invr = __shfl(inv, col, 64);
         const int ct = col >> a.gt_shift, ch = col & (a.GT - 1);
         if (ct >= ntok) continue;
         const int t = t0 + ct, h = h0 + ch;
-        if (a.nsplit > 1) {
-            float* pa = a.part_acc + (((size_t)t * a.H + h) * a.nsplit + split) * HD + x;
+        float M = fmaxf(fmaxf(s_m[0][col], s_m[1][col]), fmaxf(s_m[2][col], s_m[3][col]));
+        const float Ms = fmaxf(M, -1.0e30f);
+        float f[4], L = 0.f;
 #pragma unroll
-            for (int n = 0; n < NC; n++) pa[16 * n] = oacc[n][rr];
-            continue;
+        for (int w = 0; w < 4; w++) {
+            f[w] = __builtin_amdgcn_exp2f(s_m[w][col] - Ms);   // a wave without visible keys: exp2(-inf) = 0
+            L = fmaf(s_l[w][col], f[w], L);
         }
+        if (a.nsplit > 1 && wave == 0 && x == 0) {
+            float* pm = a.part_ml + (((size_t)t * a.H + h) * a.nsplit + split) * 2;
+            pm[0] = M * 0.69314718055994530942f;   // natural-log domain, as k_attn_combine expects
+            pm[1] = L;
+        }
+        const float invL = 1.0f / L;
+        for (int n = wave; n < NC; n += 4) {
+            float o = 0.f;
 #pragma unroll
-        for (int n = 0; n < NC; n++) {
-            const float o = oacc[n][rr] * invr;
+            for (int w = 0; w < 4; w++) o = fmaf(s_o[w][n][lane][rr], f[w], o);
             const int d = 16 * n + x;
+            if (a.nsplit > 1) {
+                a.part_acc[(((size_t)t * a.H + h) * a.nsplit + split) * HD + d] = o;
+                continue;
+            }
+            o *= invL;
             if (a.out_f32) a.out_f32[((size_t)t * a.H + h) * HD + d] = o;
             if (a.out_a16) {
                 const int kk = h * HD + d;
@@ -526,20 +544,21 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 
 // ------------------------------------------------------------------ launch
 template <int HD>
-static void launch_hd(const AttnKArgs& k, long waves, int elem_bytes) {
-    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (elem_bytes == 4)
-        hipLaunchKernelGGL((k_paged_attn<HD, float>), grid, block, 0, rt().stream, k);
-    else
-    {
-        static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 4;
-        if (HD <= 64 && pf == 8)
-            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, rt().stream, k);
-        else if (HD <= 64 && pf == 6)
-            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 6 : 2)>), grid, block, 0, rt().stream, k);
-        else
-            hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 4 : 2)>), grid, block, 0, rt().stream, k);
+static void launch_hd(const AttnKArgs& k, long units, int elem_bytes) {
+    const dim3 block(256);
+    if (elem_bytes == 4) {   // fp32 rows: `units` are waves, four independent items per workgroup
+        hipLaunchKernelGGL((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, rt().stream, k);
+        return;
     }
+    // fp16 pages: `units` are workgroups of four cooperating waves
+    const dim3 grid((unsigned)units);
+    static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 4;
+    if (HD <= 64 && pf == 8)
+        hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, rt().stream, k);
+    else if (pf == 2 || HD > 64)
+        hipLaunchKernelGGL((k_paged_attn16<HD, 2>), grid, block, 0, rt().stream, k);
+    else
+        hipLaunchKernelGGL((k_paged_attn16<HD, 4>), grid, block, 0, rt().stream, k);
 }
 
 extern "C" float nvllm_host_attn_scale(int head_dim);
@@ -562,14 +581,18 @@ void launch_paged_attention(const AttnArgs& a) {
     if (a.pool.elem_bytes == 2 && !a.tables) NVLLM_FATAL("an fp16 KV pool is always paged");
     const long base_items = (long)a.n_runs * NG;
     const int pages = (a.max_pos + 16) / 16;
-    // Work items are cut into key slices until about this many waves exist.  The fp32
-    // kernel is bound by its own instruction stream and wants 2 waves per SIMD; the
-    // fp16 kernel is bound by memory and by per-wave fixed costs (descriptor, Q,
-    // partials) and is fastest with 3 waves per CU, 4 pages in flight each.
-    static const int env_waves = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 0;
-    const int target_waves = env_waves > 0 ? env_waves : (a.pool.elem_bytes == 2 ? 768 : 2048);
-    int nsplit = (int)((target_waves + base_items - 1) / base_items);
-    if (nsplit > (pages + 1) / 2) nsplit = (pages + 1) / 2;   // at least two pages per slice
+    // Work items are cut into key slices until the chip is full.  fp32 rows: a unit is
+    // a wave (the kernel is bound by its own instruction stream: 2 waves per SIMD).
+    // fp16 pages: a unit is a workgroup whose four waves share an item and merge in
+    // LDS; one workgroup per CU streams at the HBM rate, so slices -- whose partials
+    // cost a round trip through memory and a merge launch -- are only cut when there
+    // are fewer items than CUs.
+    static const int env_units = getenv("NVLLM_ATTN_WAVES") ? atoi(getenv("NVLLM_ATTN_WAVES")) : 0;
+    const bool wg_items = a.pool.elem_bytes == 2;
+    const int target = env_units > 0 ? env_units : (wg_items ? rt().num_cus : 2048);
+    int nsplit = (int)((target + base_items / 2) / base_items);
+    const int min_pages = wg_items ? 8 : 2;   // pages per slice worth a slice
+    if (nsplit > (pages + min_pages - 1) / min_pages) nsplit = (pages + min_pages - 1) / min_pages;
     if (nsplit < 1) nsplit = 1;
     const long waves = base_items * nsplit;
 
