@@ -552,7 +552,9 @@ static void launch_hd(const AttnKArgs& k, long units, int elem_bytes) {
     }
     // fp16 pages: `units` are workgroups of four cooperating waves
     const dim3 grid((unsigned)units);
-    static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 4;
+    // pages in flight per wave: two already cover the per-CU fetch rate (one workgroup
+    // per CU, ~10 B/clk); deeper rings measured slower
+    static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 2;
     if (HD <= 64 && pf == 8)
         hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, rt().stream, k);
     else if (pf == 2 || HD > 64)
