@@ -234,6 +234,32 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     }
 
     STAMP(2);
+    // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
+    // so that they travel while the K split is being closed (every workgroup does it;
+    // only the one that ends up running the epilogue uses them).  Indices are clamped,
+    // not predicated: unconditional loads.
+    const GemmEpilogue& ep = p.e;
+    float4 pf_x[ROUNDS][IPT], pf_g[ROUNDS][IPT];
+    int pf_pos = 0, pf_row = -1;
+    if (EPI == GemmEpilogue::RESID_A16) {
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = min((int)threadIdx.x + q * NW * 64, ITEMS - 1);
+                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+                const int t = min(tb0 * 16 + j * 16 + (l & 15), p.T - 1);
+                const int n = min((nb0 + 2 * h + i) * 16 + 4 * (l >> 4), p.N - 4);
+                pf_x[h][q] = *reinterpret_cast<const float4*>(ep.x + (size_t)t * p.N + n);
+                pf_g[h][q] = *reinterpret_cast<const float4*>(ep.gain_next + n);
+            }
+    }
+    if (EPI == GemmEpilogue::ROPE_KV) {   // all items of a thread belong to one token
+        const int e = min((int)threadIdx.x, ITEMS - 1);
+        const int t = min(tb0 * 16 + ((e >> 6) % TB) * 16 + (e & 15), p.T - 1);
+        pf_pos = ep.pos[t];
+        pf_row = ep.kv_row[t];
+    }
     // ---- 1. sum the waves' partial tiles through LDS, two row blocks per round.
     // Afterwards thread `e` (item e = threadIdx.x + q * NW*64) owns, per round h, the
     // float4 for token t(e) and features n(h, e) .. n+3.
@@ -314,7 +340,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 
     STAMP(6);
     // ---- 3. epilogue on complete sums
-    const GemmEpilogue& ep = p.e;
     if (ep.ss_in != nullptr) {
         constexpr int PARTS = (NW * 64) / (TB * 16);
         __syncthreads();
@@ -377,8 +402,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             } else if (EPI == GemmEpilogue::RESID_A16) {
                 if (live) {
                     float* xr = ep.x + (size_t)t * p.N + n;
-                    const float4 xo = *reinterpret_cast<const float4*>(xr);
-                    const float4 g = *reinterpret_cast<const float4*>(ep.gain_next + n);
+                    const float4 xo = pf_x[h][q];
+                    const float4 g = pf_g[h][q];
                     // residual add as the reference's accum(): x = x + branch (layers.c:163-168)
                     const float xn[4] = {__fadd_rn(xo.x, y[0]), __fadd_rn(xo.y, y[1]), __fadd_rn(xo.z, y[2]), __fadd_rn(xo.w, y[3])};
                     *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
@@ -388,10 +413,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                 }
             } else {  // ROPE_KV
                 if (live) {
-                    const int pos = ep.pos[t];
                     if (n < ep.QD + ep.KD) {   // q or k: rotate the two pairs of this float4 (layers.c:118-141)
                         const int d = (n < ep.QD ? n : n - ep.QD) % ep.hd;
-                        const float2* tab = ep.rope + (size_t)pos * (ep.hd >> 1) + (d >> 1);
+                        const float2* tab = ep.rope + (size_t)pf_pos * (ep.hd >> 1) + (d >> 1);
                         const float2 c0 = tab[0], c1 = tab[1];
                         const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
                         y[0] = __fsub_rn(__fmul_rn(a0, c0.x), __fmul_rn(b0, c0.y));
@@ -401,10 +425,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                     }
                     if (n < ep.QD) {
                         *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
-                    } else if (t < ep.write_limit) {
-                        const int* table = ep.tables + ep.tbl_off[ep.seq[t]];
-                        const long block = table[pos / ep.bs];
-                        const int key = pos % ep.bs;
+                    } else if (pf_row >= 0) {
+                        const long block = pf_row / ep.bs;
+                        const int key = pf_row % ep.bs;
                         const bool is_k = n < ep.QD + ep.KD;
                         const int c = is_k ? n - ep.QD : n - ep.QD - ep.KD;
                         KVT* pool = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off;

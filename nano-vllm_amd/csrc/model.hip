@@ -316,11 +316,10 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         e1.kind = GemmEpilogue::ROPE_KV;
         e1.ss_in = ss_a; e1.ss_tiles = ssn; e1.d_in = D; e1.eps = eps;
         e1.q_out = s->q; e1.QD = QD; e1.KD = KD; e1.hd = hd;
-        e1.pos = st.d_pos; e1.seq = st.d_seq; e1.tbl_off = st.d_tbl_off; e1.tables = st.d_tables;
+        e1.pos = st.d_pos; e1.kv_row = st.d_kv_row;
         e1.rope = rope;
         e1.pool_k = pool.k; e1.pool_v = pool.v; e1.kv_elem_bytes = pool.elem_bytes; e1.bs = pool.block_size;
         e1.layer_off = (long)l * pool.layer_stride;
-        e1.write_limit = st.write_limit;
         launch_gemm(wqkv, lp.qkv, QD + 2 * KD, a16_x, T, e1, 0, PC_GEMM_QKV);
         // attention over the block table -> fp16 hi/lo tiles                     (model.c:380-383)
         AttnArgs at{};

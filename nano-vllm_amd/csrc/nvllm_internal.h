@@ -163,16 +163,13 @@ struct GemmEpilogue {
     float* q_out = nullptr;
     int QD = 0, KD = 0, hd = 0;
     const int* pos = nullptr;
-    const int* seq = nullptr;
-    const int* tbl_off = nullptr;
-    const int* tables = nullptr;
+    const int* kv_row = nullptr;   // per token: pool row (block * bs + slot) for its K/V, -1 = do not store
     const float2* rope = nullptr;
     void* pool_k = nullptr;
     void* pool_v = nullptr;
     int kv_elem_bytes = 4;
     int bs = 16;
     long layer_off = 0;
-    int write_limit = 0;
 };
 // out = A16[T, K] x W[N, K]^T followed by the epilogue.  Returns the K-split used.
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,

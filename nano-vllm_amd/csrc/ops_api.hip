@@ -91,7 +91,18 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
         }
     }
     s.n_runs = (int)runs.size() / 4;
-    const size_t n_ints = (size_t)(tokens ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) +
+    // where each token's K/V row goes: resolves position -> (block table entry, slot) on
+    // the host so the kernels that store K/V need one load instead of a chain of three
+    std::vector<int> kv_row;
+    if (tables || single) {
+        kv_row.resize(T);
+        for (int t = 0; t < T; t++) {
+            const int p = pos_arr ? pos_arr[t] : pos0 + t;
+            const BlockTable* bt = single ? single : tables[seq_ids ? seq_ids[t] : 0];
+            kv_row[t] = t < s.write_limit ? bt->block_indices[p / block_size] * block_size + p % block_size : -1;
+        }
+    }
+    const size_t n_ints = (size_t)(tokens ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) + kv_row.size() +
                           (output_indices ? B : 0) + n_seqs + total_tbl + runs.size() + 64;
     int* host = pinned_ints(n_ints);
     int* dev = (int*)ws_get(WS_STEP, n_ints * sizeof(int));
@@ -107,6 +118,7 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
     s.d_pos = put(pos_arr, T);
     s.d_seq = put(seq_ids, T);
     s.d_out_idx = put(output_indices, B);
+    s.d_kv_row = kv_row.empty() ? nullptr : put(kv_row.data(), kv_row.size());
     s.d_tbl_off = nullptr;
     s.d_tables = nullptr;
     if (tables || single) {

@@ -15,6 +15,7 @@ struct StepArrays {
     int* d_out_idx;   // [B]
     int* d_tbl_off;   // [n_seqs]   start of each sequence's table inside d_tables
     int* d_tables;    // concatenated logical->physical block maps
+    int* d_kv_row;    // [T] pool row (block * block_size + slot) where the token's K/V go, -1: not stored
     int* d_runs;      // [n_runs][4] (first token, count, last position, table offset): attention work items
     int n_runs;
     long kv_positions;
