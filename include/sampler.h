@@ -32,8 +32,13 @@ void build_sampler(Sampler* s, int vocab_size, float temperature, float topp,
  * maximum (strict '>' scan, reference src/sampler.c:86-97).  In the HIP library
  * a row that belongs to the most recent transformer_batch call is answered from
  * the arg-max computed on the GPU during that call; any other row is reduced by
- * the same kernel after an upload.  temperature > 0: reference
- * src/sampler.c:100-139 (in-place softmax of the row, rand() coin, top-p). */
+ * the same kernel after an upload.  temperature > 0 (reference
+ * src/sampler.c:100-139): the GPU turns the rows of the most recent pass into
+ * softmax(logits / temperature) and compacts the nucleus candidates
+ * (prob >= (1 - topp) / (n - 1), in index order); the host sorts them with the
+ * reference's comparator and draws with the reference's coin, libc rand()
+ * seeded by build_sampler.  The row is NOT rewritten in place (the reference
+ * leaves the probabilities in it; its driver never reads them). */
 int sample(Sampler* s, float* logits);
 
 #ifdef __cplusplus

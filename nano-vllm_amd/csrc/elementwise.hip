@@ -531,6 +531,95 @@ void launch_argmax(int* out, const float* logits, int B, int V) {
     hipLaunchKernelGGL(k_argmax, dim3(B), dim3(1024), 0, rt().stream, out, logits, V);
 }
 
+// Temperature softmax of each row plus the candidate filter of nucleus sampling
+// (reference sampler.c:100-121 and :41-52): probs[r, i] = softmax(logits[r, :] / T)[i];
+// when cutoff >= 0 the entries with prob >= cutoff are compacted, IN INDEX ORDER (the
+// order in which the reference's loop collects them, i.e. the input order of its
+// qsort), into cand[r, 0 .. min(count, cap)), and count[r] is their number.
+// One workgroup per row; each thread owns a contiguous chunk of the row.
+__global__ __launch_bounds__(1024) void k_sample_prep(float* __restrict__ probs, const float* __restrict__ logits,
+                                                      int V, float temperature, float cutoff,
+                                                      ProbIndex* __restrict__ cand, int cap, int* __restrict__ count) {
+    __shared__ float s_red[16];
+    __shared__ int s_cnt[16];
+    __shared__ float s_bcast;
+    const int r = blockIdx.x;
+    const float* row = logits + (size_t)r * V;
+    float* prow = probs + (size_t)r * V;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // max of logits / T
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, __fdiv_rn(row[i], temperature));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wid] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_red[0];
+        for (int w = 1; w < nw; w++) m = fmaxf(m, s_red[w]);
+        s_bcast = m;
+    }
+    __syncthreads();
+    mx = s_bcast;
+    __syncthreads();
+    // exp and denominator
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float e = expf(__fsub_rn(__fdiv_rn(row[i], temperature), mx));
+        prow[i] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) s_red[wid] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float d = 0.f;
+        for (int w = 0; w < nw; w++) d += s_red[w];
+        s_bcast = d;
+    }
+    __syncthreads();
+    const float denom = s_bcast;
+    // normalise; count the candidates of this thread's contiguous chunk
+    const int chunk = (V + blockDim.x - 1) / blockDim.x;
+    const int i0 = min(V, (int)threadIdx.x * chunk), i1 = min(V, i0 + chunk);
+    int mine = 0;
+    for (int i = i0; i < i1; i++) {
+        const float pr = __fdiv_rn(prow[i], denom);
+        prow[i] = pr;
+        mine += (cutoff >= 0.f && pr >= cutoff) ? 1 : 0;
+    }
+    if (cutoff < 0.f) return;
+    // exclusive scan of the per-thread counts: within the wave, then across waves
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_cnt[wid] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wid; w++) base += s_cnt[w];
+    int at = base + incl - mine;
+    if (threadIdx.x == blockDim.x - 1) count[r] = base + incl;
+    ProbIndex* crow = cand + (size_t)r * cap;
+    for (int i = i0; i < i1; i++) {
+        const float pr = prow[i];
+        if (pr >= cutoff) {
+            if (at < cap) {
+                crow[at].prob = pr;
+                crow[at].index = i;
+            }
+            at++;
+        }
+    }
+}
+void launch_sample_prep(float* probs, const float* logits, int B, int V, float temperature, float cutoff,
+                        ProbIndex* cand, int cap, int* count) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)B * V * 8.0, 0);
+    hipLaunchKernelGGL(k_sample_prep, dim3(B), dim3(1024), 0, rt().stream, probs, logits, V, temperature, cutoff, cand,
+                       cap, count);
+}
+
 // ------------------------------------------------------ layout converters
 // row-major fp16 [N, K] -> tile order, zero padded to whole tiles
 __global__ __launch_bounds__(256) void k_tile_weights(__half* __restrict__ tiles,

@@ -45,6 +45,7 @@ static int g_last_outputs = 0;
 static const float* g_last_logits_host = nullptr;
 static const float* g_last_logits_dev = nullptr;
 static int g_last_vocab = 0;
+static long g_pass_serial = 0;         // bumped by every forward pass
 
 static void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
     if (fread(dst, 1, bytes, f) != bytes) {
@@ -391,6 +392,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));  // the call is synchronous, like the CPU reference
     g_last_outputs = B;
+    g_pass_serial++;
     g_last_logits_host = s->logits;
     g_last_logits_dev = d_logits;
     g_last_vocab = V;
@@ -411,12 +413,128 @@ void build_sampler(Sampler* s, int vocab_size, float temperature, float topp, un
     srand((unsigned int)seed);  // reference sampler.c:26
 }
 
+// ---- temperature > 0 (reference sampler.c:100-139).  The GPU turns every row of the
+// most recent forward pass into probabilities and filters the nucleus candidates
+// (one launch for all rows, on the first sample() call after the pass); the host
+// receives the few candidates of each row, sorts them with the reference's comparator
+// and walks the cumulative sums with the reference's libc rand() coin.
+constexpr int SAMPLE_CAP = 1024;          // candidates kept per row; fuller rows take the whole-row path
+static long g_prep_serial = -1;           // pass whose rows are prepared ...
+static float g_prep_temp = 0.f, g_prep_topp = 0.f;   // ... with these settings
+static float* g_probs_dev = nullptr;      // [rows, V] of the prepared pass (workspace)
+static ProbIndex* g_cand_host = nullptr;  // pinned [cap_rows, SAMPLE_CAP]
+static int* g_count_host = nullptr;       // pinned [cap_rows]
+static int g_cand_rows = 0;
+
+static int by_prob_desc(const void* a, const void* b) {   // sampler.c:29-35
+    const float pa = ((const ProbIndex*)a)->prob, pb = ((const ProbIndex*)b)->prob;
+    if (pa > pb) return -1;
+    if (pa < pb) return 1;
+    return 0;
+}
+
+// sampler.c:54-81 on an already filtered candidate list
+static int nucleus_pick(ProbIndex* c, int n, float topp, float coin) {
+    qsort(c, (size_t)n, sizeof(ProbIndex), by_prob_desc);
+    float mass = 0.0f;
+    int last = n - 1;
+    for (int i = 0; i < n; i++) {
+        mass += c[i].prob;
+        if (mass > topp) {
+            last = i;
+            break;
+        }
+    }
+    const float r = coin * mass;
+    float cdf = 0.0f;
+    for (int i = 0; i <= last; i++) {
+        cdf += c[i].prob;
+        if (r < cdf) return c[i].index;
+    }
+    return c[last].index;
+}
+
+static void prepare_rows(const float* logits_dev, int rows, int V, float temperature, float topp) {
+    const bool nucleus = topp > 0.f && topp < 1.f;
+    const float cutoff = nucleus ? (1.0f - topp) / (float)(V - 1) : -1.0f;   // sampler.c:47
+    if (rows > g_cand_rows) {
+        if (g_cand_host) HIP_CHECK(hipHostFree(g_cand_host));
+        if (g_count_host) HIP_CHECK(hipHostFree(g_count_host));
+        g_cand_rows = rows + 64;
+        HIP_CHECK(hipHostMalloc((void**)&g_cand_host, (size_t)g_cand_rows * SAMPLE_CAP * sizeof(ProbIndex), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&g_count_host, (size_t)g_cand_rows * sizeof(int), hipHostMallocDefault));
+    }
+    g_probs_dev = (float*)ws_get(WS_MISC, (size_t)rows * V * sizeof(float));
+    char* scratch = (char*)ws_get(WS_MISC2, (size_t)rows * (SAMPLE_CAP * sizeof(ProbIndex) + sizeof(int)) + 256);
+    ProbIndex* cand_dev = (ProbIndex*)scratch;
+    int* count_dev = (int*)(scratch + (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex));
+    launch_sample_prep(g_probs_dev, logits_dev, rows, V, temperature, cutoff, cand_dev, SAMPLE_CAP, count_dev);
+    if (nucleus) {
+        HIP_CHECK(hipMemcpyAsync(g_count_host, count_dev, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+        HIP_CHECK(hipMemcpyAsync(g_cand_host, cand_dev, (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex), hipMemcpyDeviceToHost, rt().stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(rt().stream));
+}
+
+// one prepared row -> token, with the reference's coin
+static int pick_from_row(Sampler* s, int row, int V) {
+    const float coin = (float)rand() / (float)RAND_MAX;   // sampler.c:124
+    const bool nucleus = s->topp > 0.f && s->topp < 1.f;
+    if (nucleus && g_count_host[row] <= SAMPLE_CAP)
+        return nucleus_pick(g_cand_host + (size_t)row * SAMPLE_CAP, g_count_host[row], s->topp, coin);
+    // whole-row path: plain sampling (sampler.c:126-134), or a nucleus too wide for the candidate buffer
+    float* pr = (float*)malloc((size_t)V * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(pr, g_probs_dev + (size_t)row * V, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
+    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    int tok = V - 1;
+    if (!nucleus) {
+        float cdf = 0.0f;
+        for (int i = 0; i < V; i++) {
+            cdf += pr[i];
+            if (coin < cdf) {
+                tok = i;
+                break;
+            }
+        }
+    } else {
+        const float cutoff = (1.0f - s->topp) / (float)(V - 1);
+        int n = 0;
+        for (int i = 0; i < V; i++)
+            if (pr[i] >= cutoff) {
+                s->probindex[n].index = i;
+                s->probindex[n].prob = pr[i];
+                n++;
+            }
+        tok = nucleus_pick(s->probindex, n, s->topp, coin);
+    }
+    free(pr);
+    return tok;
+}
+
 int sample(Sampler* s, float* logits) {
     ensure_init();
-    if (s->temperature != 0.0f)
-        NVLLM_FATAL("sample(): temperature > 0 is not available on the GPU path yet; link the reference's "
-                    "sampler.c (it works on the host-visible logits) or use temperature 0");
     const int V = s->vocab_size;
+    if (s->temperature != 0.0f) {
+        if (g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
+            const size_t d = (size_t)(logits - g_last_logits_host);
+            if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) {
+                // a row of the most recent forward pass: its logits are still in HBM
+                if (g_prep_serial != g_pass_serial || g_prep_temp != s->temperature || g_prep_topp != s->topp) {
+                    prepare_rows(g_last_logits_dev, g_last_outputs, V, s->temperature, s->topp);
+                    g_prep_serial = g_pass_serial;
+                    g_prep_temp = s->temperature;
+                    g_prep_topp = s->topp;
+                }
+                return pick_from_row(s, (int)(d / (size_t)V), V);
+            }
+        }
+        // any other host row: upload it and prepare it alone
+        float* dev = (float*)ws_get(WS_SAMPLE, (size_t)V * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(dev, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice, rt().stream));
+        prepare_rows(dev, 1, V, s->temperature, s->topp);
+        g_prep_serial = -1;   // the prepared buffers no longer describe the last pass
+        return pick_from_row(s, 0, V);
+    }
     // a row of the most recent forward pass: answered from the arg-max the GPU already computed
     if (g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
         const size_t d = (size_t)(logits - g_last_logits_host);

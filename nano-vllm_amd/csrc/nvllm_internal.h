@@ -97,6 +97,7 @@ enum WsSlot {
     WS_STEP,        // per-call integer arrays (tokens, pos, seq ids, tables ...)
     WS_MISC,
     WS_MISC2,
+    WS_SAMPLE,      // a logits row handed to sample() that is not part of the last forward pass
     WS_COUNT
 };
 void* ws_get(WsSlot slot, size_t bytes);
@@ -258,6 +259,10 @@ void launch_swiglu(float* out, const float* g, const float* u, long n);
 void launch_accum(float* a, const float* b, long n);
 void launch_softmax(float* x, int n);
 void launch_argmax(int* out, const float* logits, int B, int V);
+// probs = softmax(logits / temperature) per row; cutoff >= 0 also compacts the entries >= cutoff, in
+// index order, into cand[row][0..cap) and counts them (count may exceed cap: the row did not fit)
+void launch_sample_prep(float* probs, const float* logits, int B, int V, float temperature, float cutoff,
+                        ProbIndex* cand, int cap, int* count);
 void launch_tile_weights(__half* tiles, const __half* rowmajor, int N, int K, long nb_stride);
 void launch_f32_to_f16(__half* dst, const float* src, size_t n);
 void launch_f16_to_f32(float* dst, const __half* src, size_t n);

@@ -68,6 +68,50 @@ def test_fp16_kv_pool_keeps_greedy_parity(hip, oracle, tmp_models):
     assert worst < LOGITS_TOL / 10, worst
 
 
+@pytest.mark.parametrize("temperature,topp", [(0.8, 0.9), (1.3, 0.5), (1.0, 1.0)])
+def test_temperature_and_nucleus_sampling_follow_the_reference(hip, oracle, tmp_models, temperature, topp):
+    """sample() with temperature > 0 (reference sampler.c:100-139): the GPU computes the
+    probabilities and filters the nucleus candidates, the host sorts them and draws with
+    libc rand() seeded like the reference, so the SAME tokens must come out as from the
+    oracle run with the same seed.  topp = 1.0 is the plain-sampling branch."""
+    path, shape = tmp_models("tiny")
+    prompts = synth.make_requests(3, 4, 20, shape.vocab_size, seed=21)
+    kw = dict(n_new=40, arrivals=[0, 1, 1], chunk_size=8, temperature=temperature, topp=topp, seed=1234)
+    o = util.run_engine(oracle, path, prompts, **kw)      # srand(seed) happens in build_sampler: run one after the other
+    g = util.run_engine(hip, path, prompts, **kw)
+    for a, b in zip(g["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+    hip.nvllm_set_logits_mode(1)                           # logits stay in HBM: same answer
+    try:
+        g2 = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_logits_mode(0)
+    for a, b in zip(g2["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_sample_on_rows_outside_the_forward_pass(hip, oracle):
+    """sample() handed an arbitrary host row (not one of the last forward pass)."""
+    import ctypes as C
+    V = 1000
+    r = np.random.Generator(np.random.PCG64(8))
+    rows = (r.standard_normal((12, V)) * 3).astype(np.float32)
+    res = {}
+    for lib in (oracle, hip):
+        smp = capi.Sampler()
+        lib.build_sampler(C.byref(smp), V, 0.7, 0.85, 99)
+        out = []
+        for k in range(rows.shape[0]):
+            row = rows[k].copy()
+            out.append(lib.sample(C.byref(smp), row.ctypes.data_as(C.POINTER(C.c_float))))
+        smp.temperature = 0.0
+        row = rows[3].copy()
+        out.append(lib.sample(C.byref(smp), row.ctypes.data_as(C.POINTER(C.c_float))))
+        res[lib.kind] = out
+    assert res["hip"] == res["oracle"]
+    assert res["hip"][-1] == int(np.argmax(rows[3]))
+
+
 def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
     path, shape = tmp_models("tiny")
     prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=6)
