@@ -112,6 +112,25 @@ def test_sample_on_rows_outside_the_forward_pass(hip, oracle):
     assert res["hip"][-1] == int(np.argmax(rows[3]))
 
 
+@pytest.mark.parametrize("kv_bytes", [4, 2])
+def test_batch_of_64_sequences_matches_the_oracle(hip, oracle, tmp_models, kv_bytes):
+    """The benchmark's batch width (64 decode rows per step: the 64-token code path of
+    every projection and of attention) on the 15M shape, both pool formats."""
+    path, shape = tmp_models("stories15M", max_seq_len=256)
+    prompts = synth.make_requests(64, 3, 30, shape.vocab_size, seed=13)
+    kw = dict(n_new=12, arrivals=[(5 * i) % 4 for i in range(64)], collect_logits=True, chunk_size=32,
+              temperature=0.0, max_steps=400)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(kv_bytes)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare_runs(g, o)
+    assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), worst
+
+
 def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
     path, shape = tmp_models("tiny")
     prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=6)
@@ -143,7 +162,7 @@ def test_matmul_accepts_load_model_handles(hip, oracle, tmp_models):
                  ("w_gate", lw.w_gate, D, F), ("w_up", lw.w_up, D, F), ("w_down", lw.w_down, F, D),
                  ("lm_head", w.lm_head, D, V)]
         out = {}
-        for T in (1, 5, 40, 70):
+        for T in (1, 5, 40, 70, 512):
             rr = np.random.Generator(np.random.PCG64(100 + T))
             for name, handle, K, N in cases:
                 x = rr.standard_normal((T, K)).astype(np.float32)

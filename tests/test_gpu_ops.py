@@ -110,8 +110,8 @@ def test_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
     """Ragged batch: one 21-token prefill chunk that straddles block boundaries,
     decode rows at context lengths 1, 16, 17, 100 and 1000, scattered block tables."""
     r = rng(hd * 7 + H)
-    L, bs, S = 2, 16, 1024
-    ctx = [40, 1, 16, 17, 100, 1000]           # keys visible to the LAST token of each sequence
+    L, bs, S = 2, 16, 4096
+    ctx = [40, 1, 15, 16, 17, 100, 1000, 4096]  # keys visible to the LAST token of each sequence
     n_seqs, maxb = len(ctx), S // bs
     nb = sum((c + bs - 1) // bs for c in ctx) + 5
     ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
@@ -159,8 +159,8 @@ def test_fp16_pool_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
     coordinates; attention over the pool must match the oracle run on those rounded
     values to fp32 accuracy."""
     r = rng(hd * 11 + H)
-    L, bs, S = 2, 16, 1024
-    ctx = [40, 1, 16, 17, 100, 1000, 33]
+    L, bs, S = 2, 16, 4096
+    ctx = [40, 1, 15, 16, 17, 100, 1000, 33, 4096]
     n_seqs, maxb = len(ctx), S // bs
     nb = sum((c + bs - 1) // bs for c in ctx) + 5
     hip.nvllm_set_kv_elem_bytes(2)

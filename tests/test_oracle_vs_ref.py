@@ -95,6 +95,28 @@ def test_forward_pass_and_scheduler(oracle, ref, tmp_models, name, chunk, dtype,
         np.testing.assert_array_equal(x, y)
 
 
+def test_allocation_trace_of_a_64_sequence_run(oracle, ref, tmp_models):
+    """Integer bookkeeping at the benchmark's width: 64 sequences, staggered arrivals,
+    chunked prefill, recycling off (the reference never frees).  The allocation trace
+    (seq, logical block, physical block), the block tables and the ragged batches of
+    every step must be bit-identical, and physical ids start at 0, 1, 2, ..."""
+    path, shape = tmp_models("tiny", seed=6)
+    prompts = synth.make_requests(64, 2, 40, shape.vocab_size, seed=17)
+    arrivals = [(7 * i) % 11 for i in range(64)]
+    kw = dict(n_new=20, arrivals=arrivals, chunk_size=16, temperature=0.0, max_steps=1000)
+    a = util.run_engine(oracle, path, prompts, **kw)
+    b = util.run_engine(ref, path, prompts, **kw)
+    np.testing.assert_array_equal(a["trace"], b["trace"])
+    assert a["trace"].shape[0] >= 64
+    np.testing.assert_array_equal(a["trace"][:, 2], np.arange(a["trace"].shape[0]))   # LIFO stack pops 0,1,2,...
+    for ta, tb in zip(a["tables"], b["tables"]):
+        np.testing.assert_array_equal(ta, tb)
+    assert len(a["steps"]) == len(b["steps"])
+    for sa, sb in zip(a["steps"], b["steps"]):
+        for key in ("tokens", "pos", "seq_ids", "output_indices", "sampled"):
+            np.testing.assert_array_equal(sa[key], sb[key])
+
+
 def test_two_sequence_demo_matches_reference_binary(oracle, tmp_path):
     """The driver restated in host/engine.c against the reference's UNMODIFIED
     main() (oracle/_ref/nano_vllm_ref): same model, a tokenizer whose pieces are
