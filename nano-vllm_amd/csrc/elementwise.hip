@@ -75,35 +75,6 @@ __device__ __forceinline__ void store_a16_8(__half* a16, int t, int k, int Kb, c
 }
 
 // ---------------------------------------------------------------- embedding
-// x[t, :] = float(table[tokens[t], :])   (reference model.c:352-355)
-__global__ void k_embed(float* __restrict__ x, const __half* __restrict__ table,
-                        const int* __restrict__ tokens, int D) {
-    const int t = blockIdx.x;
-    const __half* row = table + (size_t)tokens[t] * D;
-    float* dst = x + (size_t)t * D;
-    for (int i = threadIdx.x * 8; i < D; i += blockDim.x * 8) {
-        if (i + 8 <= D) {
-            const Half8 h = *reinterpret_cast<const Half8*>(row + i);
-            float4 a, b;
-            a.x = __half2float(h.v[0]); a.y = __half2float(h.v[1]);
-            a.z = __half2float(h.v[2]); a.w = __half2float(h.v[3]);
-            b.x = __half2float(h.v[4]); b.y = __half2float(h.v[5]);
-            b.z = __half2float(h.v[6]); b.w = __half2float(h.v[7]);
-            *reinterpret_cast<float4*>(dst + i) = a;
-            *reinterpret_cast<float4*>(dst + i + 4) = b;
-        } else {
-            for (int j = i; j < D; j++) dst[j] = __half2float(row[j]);
-        }
-    }
-}
-
-void launch_embed(float* x, const __half* table, const int* tokens, int T, int D) {
-    if (T <= 0) return;
-    if (D % 8) NVLLM_FATAL("embedding width %d is not a multiple of 8", D);
-    ProfScope ps(PC_EMBED, (double)T * D * 6, 0);
-    hipLaunchKernelGGL(k_embed, dim3(T), dim3(256), 0, rt().stream, x, table, tokens, D);
-}
-
 // Embedding gather fused with the first layer's input preparation: fp32 residual
 // row, the row times the first RMSNorm gain as fp16 hi/lo tiles, and the sum of
 // squares per 64-feature tile (the consumer projection turns those into 1/rms).
@@ -170,69 +141,30 @@ void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const floa
 }
 
 // ------------------------------------------------------------------ RMSNorm
-// One workgroup per output row.  Pass 1: (optionally) fold in the split-K slabs of
-// the previous projection, x += sum_s slab[s], and accumulate the sum of squares;
-// pass 2: re-read the thread's own elements (L1/L2-hot) and write the normalised
-// row, either fp32 row-major or fp16 hi/lo tiles.
-// Arithmetic per element as reference layers.c:32-35: r = 1/sqrtf(ss/D + eps),
-// out = (x * r) * g.
-template <bool A16OUT>
-__global__ __launch_bounds__(256) void k_rmsnorm(float* out_f32, __half* out_a16, float* x,
-                                                 const float* __restrict__ gain,
-                                                 const float* __restrict__ slabs, int ksplit,
-                                                 long slab_stride, int D, float eps,
-                                                 const int* __restrict__ gather) {
+// ops.h rms_norm (reference layers.c:23-38).  One workgroup per row; arithmetic per
+// element as layers.c:32-35: r = 1/sqrtf(ss/D + eps), out = (x * r) * g.  (Inside the
+// forward pass RMSNorm is folded into the projections, see gemm.hip.)
+__global__ __launch_bounds__(256) void k_rmsnorm(float* out, const float* x, const float* __restrict__ gain, int D,
+                                                 float eps) {
     __shared__ float red[17];
-    const int r = blockIdx.x;
-    const int ts = gather ? gather[r] : r;
-    float* xr = x + (size_t)ts * D;
+    const float* xr = x + (size_t)blockIdx.x * D;
     float ss = 0.f;
     for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
-        float4 v = *reinterpret_cast<const float4*>(xr + i);
-        if (ksplit > 0) {
-            // issue every slab load before the first add: a load-add chain would pay
-            // one L2 round trip per slab
-            for (int s0 = 0; s0 < ksplit; s0 += 8) {
-                float4 p[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (s0 + u < ksplit)
-                        p[u] = *reinterpret_cast<const float4*>(slabs + (s0 + u) * slab_stride + (size_t)ts * D + i);
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (s0 + u < ksplit) { v.x += p[u].x; v.y += p[u].y; v.z += p[u].z; v.w += p[u].w; }
-            }
-            // pass 2 re-reads the row, so the folded sum goes back to x in every mode
-            // (rows named twice by `gather` would race; output rows are distinct)
-            *reinterpret_cast<float4*>(xr + i) = v;
-        }
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);
         ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     ss = block_sum(ss, red);
     const float rinv = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)D), eps)));
-    const int Kb = (D + 31) >> 5;
-    if (A16OUT) {
-        for (int i = threadIdx.x * 8; i < Kb * 32; i += blockDim.x * 8) {
-            float y[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int c = i + j;
-                y[j] = c < D ? __fmul_rn(__fmul_rn(xr[c], rinv), gain[c]) : 0.f;
-            }
-            store_a16_8(out_a16, r, i, Kb, y);
-        }
-    } else {
-        float* o = out_f32 + (size_t)r * D;
-        for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(xr + i);
-            const float4 g = *reinterpret_cast<const float4*>(gain + i);
-            float4 y;
-            y.x = __fmul_rn(__fmul_rn(v.x, rinv), g.x);
-            y.y = __fmul_rn(__fmul_rn(v.y, rinv), g.y);
-            y.z = __fmul_rn(__fmul_rn(v.z, rinv), g.z);
-            y.w = __fmul_rn(__fmul_rn(v.w, rinv), g.w);
-            *reinterpret_cast<float4*>(o + i) = y;
-        }
+    float* o = out + (size_t)blockIdx.x * D;
+    for (int i = threadIdx.x * 4; i < D; i += blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + i);   // out may alias x: each thread rewrites what it read
+        const float4 g = *reinterpret_cast<const float4*>(gain + i);
+        float4 y;
+        y.x = __fmul_rn(__fmul_rn(v.x, rinv), g.x);
+        y.y = __fmul_rn(__fmul_rn(v.y, rinv), g.y);
+        y.z = __fmul_rn(__fmul_rn(v.z, rinv), g.z);
+        y.w = __fmul_rn(__fmul_rn(v.w, rinv), g.w);
+        *reinterpret_cast<float4*>(o + i) = y;
     }
 }
 
@@ -249,22 +181,11 @@ __global__ __launch_bounds__(256) void k_rmsnorm_any(float* out, const float* x,
     for (int i = threadIdx.x; i < D; i += blockDim.x) o[i] = __fmul_rn(__fmul_rn(xr[i], rinv), gain[i]);
 }
 
-void launch_rmsnorm_a16(__half* a16, float* x, const float* gain, const float* slabs, int ksplit,
-                        int Tpad, int T, int D, float eps, const int* gather, int prof_cls) {
-    if (T <= 0) return;
-    if (D % 4) NVLLM_FATAL("fused RMSNorm needs a width that is a multiple of 4, got %d", D);
-    ProfScope ps(prof_cls, (double)T * D * (4.0 * (2 + ksplit) + 4.0), 0);
-    hipLaunchKernelGGL(k_rmsnorm<true>, dim3(T), dim3(256), 0, rt().stream, (float*)nullptr, a16, x, gain,
-                       slabs, ksplit, (long)Tpad * D, D, eps, gather);
-}
-
 void launch_rmsnorm_f32(float* o, const float* x, const float* gain, int D, int T, float eps) {
     if (T <= 0) return;
     ProfScope ps(PC_RMSNORM, (double)T * D * 8.0, 0);
     if (D % 4 == 0 && ((uintptr_t)o % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)gain % 16 == 0))
-        hipLaunchKernelGGL(k_rmsnorm<false>, dim3(T), dim3(256), 0, rt().stream, o, (__half*)nullptr,
-                           const_cast<float*>(x), gain, (const float*)nullptr, 0, 0L, D, eps,
-                           (const int*)nullptr);
+        hipLaunchKernelGGL(k_rmsnorm, dim3(T), dim3(256), 0, rt().stream, o, x, gain, D, eps);
     else
         hipLaunchKernelGGL(k_rmsnorm_any, dim3(T), dim3(256), 0, rt().stream, o, x, gain, D, eps);
 }
@@ -294,26 +215,6 @@ void launch_pack_a16(__half* a16, const float* in, int T, int K) {
     ProfScope ps(PC_PACK, (double)T * K * 8.0, 0);
     hipLaunchKernelGGL(k_pack_a16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rt().stream, a16, in,
                        T, K, Kb, Tb);
-}
-
-// ------------------------------------------------------------- slab reduce
-__global__ void k_slab_reduce(float* out, const float* __restrict__ slabs, int ksplit, long slab_stride,
-                              long n, const float* residual) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float v = residual ? residual[i] : 0.f;
-        for (int s = 0; s < ksplit; s++) v += slabs[s * slab_stride + i];
-        out[i] = v;
-    }
-}
-
-void launch_slab_reduce(float* out, const float* slabs, int ksplit, int T, int Tpad, int N,
-                        const float* residual) {
-    const long n = (long)T * N;
-    if (n <= 0) return;
-    ProfScope ps(PC_ELEMWISE, (double)n * 4.0 * (ksplit + 1 + (residual ? 1 : 0)), 0);
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, rt().stream, out, slabs, ksplit,
-                       (long)Tpad * N, n, residual);
 }
 
 // --------------------------------------------------------------------- RoPE

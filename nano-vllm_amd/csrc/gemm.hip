@@ -53,21 +53,8 @@ struct GemmArgs {
     int ksplit;
     float* slab;      // [tile][slice][round][item] float4
     unsigned* counters;
-    unsigned long long* stamps;   // diagnostic builds only (-DGEMM_STAMPS): [wg][wave][8] shader clocks
     GemmEpilogue e;
 };
-
-#ifdef GEMM_STAMPS
-#define STAMP(k)                                                                                   \
-    do {                                                                                           \
-        if (p.stamps && lane == 0) {                                                               \
-            const unsigned wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    \
-            p.stamps[((size_t)wg * NW + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime();           \
-        }                                                                                          \
-    } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
 
 __device__ __forceinline__ float silu_mul(float g, float u) {
     // reference layers.c:156-158: g / (1 + expf(-g)) * u
@@ -121,14 +108,8 @@ __device__ __forceinline__ void kv_put4_strided<__half>(__half* dst, const float
 template <int NBW, int TB, int NW, int EPI, typename KVT>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
-#ifndef GEMM_RW
-#define GEMM_RW 4
-#endif
-#ifndef GEMM_RA
-#define GEMM_RA 2
-#endif
-    constexpr int RW = GEMM_RW;        // weight ring depth (K-steps in flight)
-    constexpr int RA = GEMM_RA;        // activation ring depth
+    constexpr int RW = 4;              // weight ring depth (K-steps in flight)
+    constexpr int RA = 2;              // activation ring depth
     constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
     constexpr int ITEMS = 2 * TB * 64; // float4 results per round
     constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
@@ -146,8 +127,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     const int tb0 = blockIdx.z * TB;
     const int first = kb_begin + wave;
     const int nsteps = first < kb_end ? (kb_end - first + NW - 1) / NW : 0;
-
-    STAMP(0);
     const h8_t* wp[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; i++)
@@ -200,7 +179,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         for (int j = part; j < p.e.ss_tiles; j += PARTS) ss += sp[j];
         s_part[part][tl] = ss;
     }
-    STAMP(1);
     for (int s0 = 0; s0 < nsteps; s0 += RW) {
 #pragma unroll
         for (int r = 0; r < RW; r++) {
@@ -213,15 +191,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
                     }
-#ifndef GEMM_ABL
-#define GEMM_ABL 0
-#endif
-                if (GEMM_ABL != 2 && s + RW < nsteps) {
+                if (s + RW < nsteps) {
                     const int kbw = kb_of(s + RW);
 #pragma unroll
                     for (int i = 0; i < NBW; i++) w[r][i] = __builtin_nontemporal_load(wp[i] + (size_t)kbw * 64);
                 }
-                if (GEMM_ABL != 1 && s + RA < nsteps) {
+                if (s + RA < nsteps) {
                     const int kba = kb_of(s + RA);
 #pragma unroll
                     for (int j = 0; j < TB; j++) {
@@ -232,8 +207,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             }
         }
     }
-
-    STAMP(2);
     // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
     // so that they travel while the K split is being closed (every workgroup does it;
     // only the one that ends up running the epilogue uses them).  Indices are clamped,
@@ -285,8 +258,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             v[h][q] = sum;
         }
     }
-
-    STAMP(3);
     // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
     const unsigned tile_id = blockIdx.z * gridDim.x + blockIdx.x;
     if (p.ksplit > 1) {
@@ -302,12 +273,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                                                            /*sc1: write through*/ 16);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-        STAMP(4);
         __syncthreads();
         if (threadIdx.x == 0)
             s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        STAMP(5);
         if (s_ticket != (unsigned)p.ksplit - 1) return;     // not the last slice of this tile
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -337,8 +306,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                 v[h][q] = sum;
             }
     }
-
-    STAMP(6);
     // ---- 3. epilogue on complete sums
     if (ep.ss_in != nullptr) {
         constexpr int PARTS = (NW * 64) / (TB * 16);
@@ -461,7 +428,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             if (t < p.T) ep.ss_out[(size_t)t * gridDim.x + blockIdx.x] = s_ss[0][threadIdx.x] + s_ss[1][threadIdx.x];
         }
     }
-    STAMP(7);
 }
 
 // ------------------------------------------------------------------ launch
@@ -481,21 +447,6 @@ int gemm_pick_ksplit(int N, int K, int T) {
     const int per = cdiv(Kb, ks);
     return cdiv(Kb, per);
 }
-
-#ifdef GEMM_STAMPS
-static unsigned long long* g_last_stamps = nullptr;
-static int g_last_stamp_wgs = 0;
-extern "C" int nvllm_debug_dump_stamps(const char* path) {
-    if (!g_last_stamps) return -1;
-    std::vector<unsigned long long> h((size_t)g_last_stamp_wgs * 64);
-    HIP_CHECK(hipMemcpy(h.data(), g_last_stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    FILE* f = fopen(path, "wb");
-    fwrite(&g_last_stamp_wgs, 4, 1, f);
-    fwrite(h.data(), 8, h.size(), f);
-    fclose(f);
-    return g_last_stamp_wgs;
-}
-#endif
 
 // arrival counters: zero when allocated, every launch leaves them zero again
 static unsigned* g_counters = nullptr;
@@ -546,15 +497,6 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     ks = cdiv(a.Kb, a.kb_per_split);
     a.ksplit = ks;
     a.counters = g_counters;
-    a.stamps = nullptr;
-#ifdef GEMM_STAMPS
-    {
-        static unsigned long long* g_stamps = nullptr;
-        static const char* want = getenv("NVLLM_STAMP_CLASS");
-        if (!g_stamps) { HIP_CHECK(hipMalloc((void**)&g_stamps, 4096 * 8 * 8 * 8)); HIP_CHECK(hipMemsetAsync(g_stamps, 0, 4096 * 8 * 8 * 8, rt().stream)); }
-        if (want && atoi(want) == prof_cls && tiles_n * tiles_t * ks <= 4096) { a.stamps = g_stamps; g_last_stamps = g_stamps; g_last_stamp_wgs = tiles_n * tiles_t * ks; }
-    }
-#endif
     a.slab = nullptr;
     if (ks > 1) {
         const size_t tile_bytes = (size_t)(GEMM_NBW / 2) * 2 * TB * 64 * 16;

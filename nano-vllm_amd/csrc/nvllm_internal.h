@@ -102,10 +102,7 @@ enum WsSlot {
 };
 void* ws_get(WsSlot slot, size_t bytes);
 
-// Pinned host staging for the integer arrays of one call.  stage_ints() copies
-// `n` ints into a fresh region of a pinned ring and enqueues the H2D copy into
-// `dst`; the source may be reused when it returns.
-void stage_ints(int* dst_device, const int* src_host, size_t n);
+// Pinned host staging for the integer arrays of one call.
 int* pinned_ints(size_t n);   // ring allocation, for callers that fill it themselves
 
 // RoPE angle table for (theta, head_dim), covering positions [0, min_positions):
@@ -180,15 +177,8 @@ int gemm_feature_tiles(int N);   // 64-feature tiles of a projection output = co
 void gemm_release();
 
 void launch_pack_a16(__half* a16, const float* in, int T, int K);
-void launch_slab_reduce(float* out, const float* slabs, int ksplit, int T, int Tpad, int N,
-                        const float* residual /*nullable, may alias out*/);
 void launch_matmul_f32w(float* out, const float* in, const float* w, int T, int K, int N);
 
-// x[t,:] (+= sum of slabs) ; a16 = rmsnorm(x) * g.  slabs may be null.  When
-// `gather` is non-null, row r of the output comes from x[gather[r]] and x is not
-// written.
-void launch_rmsnorm_a16(__half* a16, float* x, const float* gain, const float* slabs, int ksplit,
-                        int Tpad, int T, int D, float eps, const int* gather, int prof_cls);
 void launch_rmsnorm_f32(float* o, const float* x, const float* gain, int D, int T, float eps);
 
 struct KvPoolView {
@@ -248,7 +238,6 @@ struct AttnArgs {
 void launch_paged_attention(const AttnArgs& a);
 int attn_tokens_per_item(int H, int KVH);
 
-void launch_embed(float* x, const __half* table, const int* tokens, int T, int D);
 // x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 64j..64j+63
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
                            const float* gain, int T, int D);

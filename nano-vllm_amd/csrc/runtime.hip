@@ -67,13 +67,6 @@ int* pinned_ints(size_t n) {
     return p;
 }
 
-void stage_ints(int* dst_device, const int* src_host, size_t n) {
-    if (n == 0) return;
-    int* p = pinned_ints(n);
-    memcpy(p, src_host, n * sizeof(int));
-    HIP_CHECK(hipMemcpyAsync(dst_device, p, n * sizeof(int), hipMemcpyHostToDevice, g_rt.stream));
-}
-
 // ----------------------------------------------------------------- registry
 static std::unordered_map<const void*, WeightEntry>& registry() {
     static std::unordered_map<const void*, WeightEntry> m;
