@@ -240,6 +240,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 #pragma unroll
     for (int h = 0; h < ROUNDS; h++) {
         __syncthreads();
+        if (h == 0 && ep.ss_in != nullptr && threadIdx.x < TB * 16) {
+            // 1/rms per token from the slices gathered at the top (visible since the barrier
+            // above; read by the epilogue after the barriers below)
+            constexpr int PARTS = (NW * 64) / (TB * 16);
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
+            s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -278,46 +287,42 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != (unsigned)p.ksplit - 1) return;     // not the last slice of this tile
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
         __syncthreads();
         const float* base = p.slab + (size_t)tile_id * p.ksplit * (ROUNDS * ITEMS * 4);
+        // Every slab load of both rounds is issued before the first add: one round trip.
+        // Slice indices past the end are clamped (a repeated load), not predicated, so the
+        // loads stay unconditional; sums are taken in slice order.
 #pragma unroll
         for (int h = 0; h < ROUNDS; h++)
 #pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = threadIdx.x + q * NW * 64;
-                f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
-                if (e < ITEMS) {
-                    for (int s0 = 0; s0 < p.ksplit; s0 += 8) {   // loads first, adds after, in slice order
-                        f4_t part[8];
+            for (int q = 0; q < IPT; q++) v[h][q] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
+            f4_t part[ROUNDS][IPT][8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            if (s0 + u < p.ksplit)
-                                part[u] = *reinterpret_cast<const f4_t*>(base + ((size_t)(s0 + u) * ROUNDS * ITEMS + h * ITEMS + e) * 4);
+            for (int h = 0; h < ROUNDS; h++)
 #pragma unroll
-                        for (int u = 0; u < 8; u++)
-                            if (s0 + u < p.ksplit) sum += part[u];
+                for (int q = 0; q < IPT; q++) {
+                    const int e = min((int)threadIdx.x + q * NW * 64, ITEMS - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int sl = min(s0 + u, p.ksplit - 1);
+                        part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
                     }
                 }
-                v[h][q] = sum;
-            }
+#pragma unroll
+            for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+                for (int q = 0; q < IPT; q++)
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (s0 + u < p.ksplit) v[h][q] += part[h][q][u];
+        }
+        // ready for the next launch (nobody else touches this tile's counter any more)
+        if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- 3. epilogue on complete sums
-    if (ep.ss_in != nullptr) {
-        constexpr int PARTS = (NW * 64) / (TB * 16);
-        __syncthreads();
-        if (threadIdx.x < TB * 16) {
-            float ss = 0.f;
-#pragma unroll
-            for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
-            s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
-        }
-        __syncthreads();
-    }
     float ssq[IPT];
 #pragma unroll
     for (int q = 0; q < IPT; q++) ssq[q] = 0.f;
