@@ -129,8 +129,6 @@ def run_gpu(args, env, shape, model_path):
     lib.nvllm_set_device(env.local_rank)
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
     lib.nvllm_set_logits_mode(1)    # only token ids return to the host
-    if args.graph:
-        lib.nvllm_set_graph_mode(1)
     B = args.batch
     # sequences that finish their prefill early already decode while the others are
     # still prefilling (continuous batching), so budget those steps too
@@ -257,7 +255,6 @@ def main():
     ap.add_argument("--max-seq-len", type=int, default=2048)
     ap.add_argument("--kv-bytes", type=int, default=2, choices=(2, 4),
                     help="KV pool element size: 2 = fp16 pages (default; parity covered by the fp16-pool GPU tests), 4 = the reference's fp32 rows")
-    ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
@@ -317,8 +314,7 @@ def main():
                                    f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
                                    f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
                                    f"mean context {r['ctx']} in the timed region",
-                       "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes,
-                       "graph_replay": bool(args.graph)},
+                       "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
             "event_bracket_us": {"subtracted_per_launch": r["bracket_us"] and round(r["bracket_us"], 2),

@@ -50,10 +50,6 @@ const int* nvllm_last_argmax(int* num_outputs);
 void nvllm_set_kv_elem_bytes(int bytes);
 int  nvllm_get_kv_elem_bytes(void);
 
-/* Replay identical consecutive decode-shaped forward passes from a captured
- * hipGraph instead of launching kernel by kernel (0 = off, 1 = on). */
-void nvllm_set_graph_mode(int on);
-
 /* ---------------------------------------------------------- kernel timing */
 /* With timing on, every kernel launch is bracketed by a pair of HIP events on
  * the library stream.  Classes are small integers; nvllm_prof_name() names them. */

@@ -143,7 +143,6 @@ _HIP_ONLY = {
     "nvllm_last_argmax": (c_int_p, [c_int_p]),
     "nvllm_set_kv_elem_bytes": (_V, [_I]),
     "nvllm_get_kv_elem_bytes": (_I, []),
-    "nvllm_set_graph_mode": (_V, [_I]),
     "nvllm_prof_enable": (_V, [_I]),
     "nvllm_prof_reset": (_V, []),
     "nvllm_prof_num_classes": (_I, []),

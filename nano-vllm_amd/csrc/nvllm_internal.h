@@ -79,7 +79,6 @@ struct Runtime {
     hipStream_t stream = nullptr;
     int logits_mode = NVLLM_LOGITS_HOST;
     int kv_elem_bytes = 4;
-    int graph_mode = 0;
     int num_cus = 256;
 };
 Runtime& rt();

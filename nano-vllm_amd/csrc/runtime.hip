@@ -184,8 +184,6 @@ void ensure_init() {
     }
     const char* kv = getenv("NVLLM_KV_BYTES");
     if (kv && (atoi(kv) == 2 || atoi(kv) == 4)) g_rt.kv_elem_bytes = atoi(kv);
-    const char* gm = getenv("NVLLM_GRAPH");
-    if (gm) g_rt.graph_mode = atoi(gm) != 0;
     g_rt.inited = true;
 }
 
@@ -217,7 +215,6 @@ void nvllm_set_kv_elem_bytes(int bytes) {
     g_rt.kv_elem_bytes = bytes;
 }
 int nvllm_get_kv_elem_bytes(void) { return g_rt.kv_elem_bytes; }
-void nvllm_set_graph_mode(int on) { g_rt.graph_mode = on != 0; }
 
 void nvllm_prof_enable(int on) {
     ensure_init();
