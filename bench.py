@@ -172,38 +172,20 @@ def run_gpu(args, env, shape, model_path):
     prof = {}
     if env.rank == 0 and args.profile_steps > 0:
         lib.nvllm_prof_reset()
-        lib.device_sync()
-        tp0 = time.perf_counter()
         lib.nvllm_prof_enable(1)
         for _ in range(args.profile_steps):
             eng.step()
-        lib.device_sync()
-        prof_step_ms = (time.perf_counter() - tp0) / args.profile_steps * 1e3
         lib.nvllm_prof_enable(0)
-        # What one event pair adds to a launch: the bracketed steps run slower than the
-        # timed ones by exactly the brackets (same kernels, same data), so the difference
-        # per launch is the bracket.  (An EMPTY pair measures more than that, about
-        # nvllm_prof_event_overhead_ms(); it is reported for reference.)
-        n_launches = 0
-        for c in range(lib.nvllm_prof_num_classes()):
-            n = C.c_longlong()
-            lib.nvllm_prof_get(c, C.byref(n), None, None, None)
-            n_launches += n.value
-        plain_step_ms = elapsed / args.steps * 1e3
-        bracket_ms = max(0.0, (prof_step_ms - plain_step_ms) * args.profile_steps / max(n_launches, 1))
-        empty_pair_ms = lib.nvllm_prof_event_overhead_ms()
         for c in range(lib.nvllm_prof_num_classes()):
             n, ms, by, fl = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
             lib.nvllm_prof_get(c, C.byref(n), C.byref(ms), C.byref(by), C.byref(fl))
             if n.value:
-                prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, raw_ms=ms.value,
-                                                             total_ms=max(ms.value - n.value * bracket_ms, 1e-9),
+                prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, total_ms=ms.value,
                                                              bytes=by.value, flops=fl.value)
     hist = eng.history(0)[-4:].tolist()
     eng.close()
     return dict(elapsed=elapsed, prefill_s=prefill_s, prefill_tokens=prefill_tokens, step_bytes=step_bytes,
-                prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist,
-                bracket_us=(bracket_ms * 1e3 if prof else None), empty_pair_us=(empty_pair_ms * 1e3 if prof else None))
+                prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist)
 
 
 def cpu_baseline(args, shape, model_path):
@@ -280,7 +262,7 @@ def main():
                                ("k_paged_attn16" if args.kv_bytes == 2 else "k_paged_attn") if cls == "attn" else
                                {"attn_combine": "k_attn_combine", "argmax": "k_argmax", "embed": "k_embed_prescale"}.get(cls, cls))
             for cls, d in r["prof"].items():
-                g = by_kernel.setdefault(sym(cls), dict(launches=0, total_ms=0.0, raw_ms=0.0, bytes=0.0))
+                g = by_kernel.setdefault(sym(cls), dict(launches=0, total_ms=0.0, bytes=0.0))
                 for k in g:
                     g[k] += d[k]
             pmc = {}
@@ -294,8 +276,8 @@ def main():
                 return dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 4),
                             traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"),
-                            avg_kernel_us=round(avg_ms * 1e3, 2),   # event pair minus what the pair itself adds
-                            avg_event_pair_us=round(d["raw_ms"] / d["launches"] * 1e3, 2), launches=d["launches"],
+                            avg_kernel_us=round(avg_ms * 1e3, 2),   # dispatch begin -> end, HIP events of the launch
+                            launches=d["launches"],
                             algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
                             share_of_step=round(d["total_ms"] / args.profile_steps / ms_per_step, 3))
             roofline = roof(max(by_kernel, key=lambda k: by_kernel[k]["total_ms"]))   # the kernel the step spends most time in
@@ -317,8 +299,6 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
-            "event_bracket_us": {"subtracted_per_launch": r["bracket_us"] and round(r["bracket_us"], 2),
-                                 "empty_pair": r["empty_pair_us"] and round(r["empty_pair_us"], 2)},
             "cpu_baseline": cpu,
             "step_hbm": {"algorithmic_bytes_per_step": int(r["step_bytes"]), "achieved_GBps": round(step_gbs, 1),
                          "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},

@@ -51,8 +51,10 @@ void nvllm_set_kv_elem_bytes(int bytes);
 int  nvllm_get_kv_elem_bytes(void);
 
 /* ---------------------------------------------------------- kernel timing */
-/* With timing on, every kernel launch is bracketed by a pair of HIP events on
- * the library stream.  Classes are small integers; nvllm_prof_name() names them. */
+/* With timing on, every kernel is launched with a start and a stop event attached to
+ * its dispatch (hipExtLaunchKernelGGL), so the elapsed time is the kernel's own
+ * begin-to-end time on the library stream.  Classes are small integers;
+ * nvllm_prof_name() names them. */
 void nvllm_prof_enable(int on);
 void nvllm_prof_reset(void);
 int  nvllm_prof_num_classes(void);
@@ -61,9 +63,6 @@ const char* nvllm_prof_name(int cls);
  * (what the kernel must read+write at least once) and flops.  Resolves pending
  * events (synchronises the stream). */
 void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* bytes, double* flops);
-/* Mean elapsed time of an empty event pair on the library stream: the part of every
- * timed launch that is the bracket, not the kernel. */
-double nvllm_prof_event_overhead_ms(void);
 
 /* ------------------------------------------------------ N-sequence driver */
 /* The reference's scheduler with the sequence count as a parameter: arrival

@@ -149,7 +149,6 @@ _HIP_ONLY = {
     "nvllm_prof_name": (C.c_char_p, [_I]),
     "nvllm_prof_get": (_V, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "nvllm_prof_event_overhead_ms": (C.c_double, []),
     "nvllm_free_model": (_V, [C.POINTER(Weights)]),
 }
 

@@ -547,7 +547,7 @@ template <int HD>
 static void launch_hd(const AttnKArgs& k, long units, int elem_bytes) {
     const dim3 block(256);
     if (elem_bytes == 4) {   // fp32 rows: `units` are waves, four independent items per workgroup
-        hipLaunchKernelGGL((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, rt().stream, k);
+        NVLLM_LAUNCH((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
         return;
     }
     // fp16 pages: `units` are workgroups of four cooperating waves
@@ -556,11 +556,11 @@ static void launch_hd(const AttnKArgs& k, long units, int elem_bytes) {
     // per CU, ~10 B/clk); deeper rings measured slower
     static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 2;
     if (HD <= 64 && pf == 8)
-        hipLaunchKernelGGL((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, rt().stream, k);
+        NVLLM_LAUNCH((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, k);
     else if (pf == 2 || HD > 64)
-        hipLaunchKernelGGL((k_paged_attn16<HD, 2>), grid, block, 0, rt().stream, k);
+        NVLLM_LAUNCH((k_paged_attn16<HD, 2>), grid, block, 0, k);
     else
-        hipLaunchKernelGGL((k_paged_attn16<HD, 4>), grid, block, 0, rt().stream, k);
+        NVLLM_LAUNCH((k_paged_attn16<HD, 4>), grid, block, 0, k);
 }
 
 extern "C" float nvllm_host_attn_scale(int head_dim);
@@ -647,7 +647,7 @@ void launch_paged_attention(const AttnArgs& a) {
     if (nsplit > 1) {
         ProfScope ps(PC_ATTN_COMBINE, (double)a.T * a.H * nsplit * (a.hd + 2) * 4.0, 0);
         const long threads = (long)a.T * a.H * (a.hd / 8);
-        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, rt().stream,
+        NVLLM_LAUNCH(k_attn_combine, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                            k.part_acc, k.part_ml, a.T, a.H, a.hd, nsplit, a.out_f32, a.out_a16, k.Kb_out);
     }
 }

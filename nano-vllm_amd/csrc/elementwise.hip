@@ -113,7 +113,7 @@ void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table
     if (T <= 0) return;
     if (D % 32) NVLLM_FATAL("embedding width %d is not a multiple of 32", D);
     ProfScope ps(PC_EMBED, (double)T * D * 10, 0);
-    hipLaunchKernelGGL(k_embed_prescale, dim3(T), dim3(256), 0, rt().stream, x, a16, ss, table, tokens, gain, D,
+    NVLLM_LAUNCH(k_embed_prescale, dim3(T), dim3(256), 0, x, a16, ss, table, tokens, gain, D,
                        cdiv(D, 64));
 }
 
@@ -136,7 +136,7 @@ void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const floa
                        int K, int ss_tiles) {
     if (B <= 0) return;
     ProfScope ps(PC_PACK, (double)B * K * 8.0, 0);
-    hipLaunchKernelGGL(k_gather_a16, dim3(B), dim3(256), 0, rt().stream, dst, dst_ss, src, src_ss, idx, cdiv(K, 32),
+    NVLLM_LAUNCH(k_gather_a16, dim3(B), dim3(256), 0, dst, dst_ss, src, src_ss, idx, cdiv(K, 32),
                        ss_tiles);
 }
 
@@ -185,9 +185,9 @@ void launch_rmsnorm_f32(float* o, const float* x, const float* gain, int D, int 
     if (T <= 0) return;
     ProfScope ps(PC_RMSNORM, (double)T * D * 8.0, 0);
     if (D % 4 == 0 && ((uintptr_t)o % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)gain % 16 == 0))
-        hipLaunchKernelGGL(k_rmsnorm, dim3(T), dim3(256), 0, rt().stream, o, x, gain, D, eps);
+        NVLLM_LAUNCH(k_rmsnorm, dim3(T), dim3(256), 0, o, x, gain, D, eps);
     else
-        hipLaunchKernelGGL(k_rmsnorm_any, dim3(T), dim3(256), 0, rt().stream, o, x, gain, D, eps);
+        NVLLM_LAUNCH(k_rmsnorm_any, dim3(T), dim3(256), 0, o, x, gain, D, eps);
 }
 
 // -------------------------------------------------------------- pack to a16
@@ -213,7 +213,7 @@ void launch_pack_a16(__half* a16, const float* in, int T, int K) {
     const int Kb = cdiv(K, 32), Tb = cdiv(T, 16);
     const long total = (long)Tb * Kb * 64;
     ProfScope ps(PC_PACK, (double)T * K * 8.0, 0);
-    hipLaunchKernelGGL(k_pack_a16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rt().stream, a16, in,
+    NVLLM_LAUNCH(k_pack_a16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a16, in,
                        T, K, Kb, Tb);
 }
 
@@ -251,7 +251,7 @@ void launch_rope(float* q, float* k, const int* pos, int pos0, const float2* rop
                  int hd) {
     if (T <= 0) return;
     ProfScope ps(PC_ROPE_KV, (double)T * (H + KVH) * hd * 8.0, 0);
-    hipLaunchKernelGGL(k_rope, dim3(T), dim3(256), 0, rt().stream, q, k, pos, pos0, rope, H, KVH, hd);
+    NVLLM_LAUNCH(k_rope, dim3(T), dim3(256), 0, q, k, pos, pos0, rope, H, KVH, hd);
 }
 
 // Physical row (in units of token rows) of position p of the sequence that owns
@@ -325,12 +325,12 @@ void launch_kv_write(const float* k, const float* v, const int* pos, int pos0, c
     ProfScope ps(PC_ROPE_KV, (double)T * KD * 2 * (4.0 + pool.elem_bytes), 0);
     const long layer_off = (long)layer * pool.layer_stride;
     if (pool.elem_bytes == 4) {
-        hipLaunchKernelGGL(k_kv_write<float>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
+        NVLLM_LAUNCH(k_kv_write<float>, dim3(T), dim3(256), 0, k, v, pos, pos0, seq, tbl_off,
                            tables, (float*)pool.k, (float*)pool.v, pool.block_size, layer_off, KVH, hd);
     } else {
         if (!tables || pool.block_size != KV16_PAGE_KEYS || hd % 16)
             NVLLM_FATAL("an fp16 KV pool needs block tables, block_size 16 and head_dim %% 16 == 0");
-        hipLaunchKernelGGL(k_kv_write<__half>, dim3(T), dim3(256), 0, rt().stream, k, v, pos, pos0, seq, tbl_off,
+        NVLLM_LAUNCH(k_kv_write<__half>, dim3(T), dim3(256), 0, k, v, pos, pos0, seq, tbl_off,
                            tables, (__half*)pool.k, (__half*)pool.v, pool.block_size, layer_off, KVH, hd);
     }
 }
@@ -350,7 +350,7 @@ void launch_swiglu(float* out, const float* g, const float* u, long n) {
     if (n <= 0) return;
     ProfScope ps(PC_ELEMWISE, (double)n * 12.0, 0);
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_swiglu, dim3(blocks), dim3(256), 0, rt().stream, out, g, u, n);
+    NVLLM_LAUNCH(k_swiglu, dim3(blocks), dim3(256), 0, out, g, u, n);
 }
 
 __global__ void k_accum(float* a, const float* b, long n) {
@@ -361,7 +361,7 @@ void launch_accum(float* a, const float* b, long n) {
     if (n <= 0) return;
     ProfScope ps(PC_ELEMWISE, (double)n * 12.0, 0);
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_accum, dim3(blocks), dim3(256), 0, rt().stream, a, b, n);
+    NVLLM_LAUNCH(k_accum, dim3(blocks), dim3(256), 0, a, b, n);
 }
 
 // softmax of one vector (reference layers.c:170-186): max, exp+sum, divide
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_softmax(float* x, int n) {
 void launch_softmax(float* x, int n) {
     if (n <= 0) return;
     ProfScope ps(PC_ELEMWISE, (double)n * 16.0, 0);
-    hipLaunchKernelGGL(k_softmax, dim3(1), dim3(1024), 0, rt().stream, x, n);
+    NVLLM_LAUNCH(k_softmax, dim3(1), dim3(1024), 0, x, n);
 }
 
 // First index of the row maximum (reference sampler.c:86-97: strict '>' scan, so
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
 void launch_argmax(int* out, const float* logits, int B, int V) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
-    hipLaunchKernelGGL(k_argmax, dim3(B), dim3(1024), 0, rt().stream, out, logits, V);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V);
 }
 
 // Temperature softmax of each row plus the candidate filter of nucleus sampling
@@ -517,7 +517,7 @@ void launch_sample_prep(float* probs, const float* logits, int B, int V, float t
                         ProbIndex* cand, int cap, int* count) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * V * 8.0, 0);
-    hipLaunchKernelGGL(k_sample_prep, dim3(B), dim3(1024), 0, rt().stream, probs, logits, V, temperature, cutoff, cand,
+    NVLLM_LAUNCH(k_sample_prep, dim3(B), dim3(1024), 0, probs, logits, V, temperature, cutoff, cand,
                        cap, count);
 }
 
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_tile_weights(__half* __restrict__ tiles
 void launch_tile_weights(__half* tiles, const __half* rowmajor, int N, int K, long nb_stride) {
     const int Kb = cdiv(K, 32), Nb = cdiv(N, 16);
     const long total = (long)Nb * Kb * 64;
-    hipLaunchKernelGGL(k_tile_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rt().stream, tiles,
+    NVLLM_LAUNCH(k_tile_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tiles,
                        rowmajor, N, K, Kb, Nb, nb_stride);
 }
 
@@ -552,7 +552,7 @@ __global__ void k_f32_to_f16(__half* dst, const float* src, size_t n) {
 }
 void launch_f32_to_f16(__half* dst, const float* src, size_t n) {
     if (!n) return;
-    hipLaunchKernelGGL(k_f32_to_f16, dim3(2048), dim3(256), 0, rt().stream, dst, src, n);
+    NVLLM_LAUNCH(k_f32_to_f16, dim3(2048), dim3(256), 0, dst, src, n);
 }
 __global__ void k_f16_to_f32(float* dst, const __half* src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -560,7 +560,7 @@ __global__ void k_f16_to_f32(float* dst, const __half* src, size_t n) {
 }
 void launch_f16_to_f32(float* dst, const __half* src, size_t n) {
     if (!n) return;
-    hipLaunchKernelGGL(k_f16_to_f32, dim3(2048), dim3(256), 0, rt().stream, dst, src, n);
+    NVLLM_LAUNCH(k_f16_to_f32, dim3(2048), dim3(256), 0, dst, src, n);
 }
 
 }  // namespace nvllm

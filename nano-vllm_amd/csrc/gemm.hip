@@ -462,16 +462,16 @@ static void launch_tb(const GemmArgs& a, dim3 grid) {
     const dim3 block(GEMM_NW * 64);
     switch (a.e.kind) {
         case GemmEpilogue::F32:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, rt().stream, a);
+            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, a);
             break;
         case GemmEpilogue::SWIGLU_A16:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, rt().stream, a);
+            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, a);
             break;
         case GemmEpilogue::RESID_A16:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, rt().stream, a);
+            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, a);
             break;
         default:
-            hipLaunchKernelGGL((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, rt().stream, a);
+            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, a);
             break;
     }
 }
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void k_matmul_f32w(float* __restrict__ out, co
 void launch_matmul_f32w(float* out, const float* in, const float* w, int T, int K, int N) {
     if (T <= 0 || N <= 0) return;
     ProfScope ps(PC_GEMM_OTHER, (double)N * K * 4.0 + (double)T * (K + N) * 4.0, 2.0 * T * (double)N * K);
-    hipLaunchKernelGGL(k_matmul_f32w, dim3(cdiv(N, 4), cdiv(T, 8)), dim3(256), 0, rt().stream, out, in, w, T, K, N);
+    NVLLM_LAUNCH(k_matmul_f32w, dim3(cdiv(N, 4), cdiv(T, 8)), dim3(256), 0, out, in, w, T, K, N);
 }
 
 }  // namespace nvllm

@@ -4,6 +4,7 @@
 
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstddef>
 #include <cstdint>
@@ -127,7 +128,14 @@ enum ProfClass {
     PC_PACK,
     PC_COUNT
 };
-struct ProfScope {  // brackets launches on rt().stream with an event pair when timing is on
+hipEvent_t prof_start_event();   // events of the enclosing ProfScope, or null when timing is off
+hipEvent_t prof_stop_event();
+// Every kernel goes through this: on the library stream, with the timing events of the
+// enclosing ProfScope attached to the dispatch itself.
+#define NVLLM_LAUNCH(kernel, grid, block, shmem, ...)                                                   \
+    hipExtLaunchKernelGGL(kernel, grid, block, shmem, ::nvllm::rt().stream, ::nvllm::prof_start_event(), \
+                          ::nvllm::prof_stop_event(), 0, __VA_ARGS__)
+struct ProfScope {  // names the class of, and attaches timing events to, the ONE launch made inside it
     ProfScope(int cls, double bytes, double flops);
     ~ProfScope();
     int slot;

@@ -137,16 +137,24 @@ static hipEvent_t prof_event() {
     return e;
 }
 
+// Timing uses the start/stop events of hipExtLaunchKernelGGL: they carry the
+// dispatch's own begin and end timestamps (what a kernel trace reports), not the time
+// at which separate event packets happen to be processed before and after it.
+static hipEvent_t g_cur_start = nullptr, g_cur_stop = nullptr;
+hipEvent_t prof_start_event() { return g_cur_start; }
+hipEvent_t prof_stop_event() { return g_cur_stop; }
+
 ProfScope::ProfScope(int cls, double bytes, double flops) : slot(-1) {
     if (!g_prof_on) return;
     ProfRec r{cls, prof_event(), prof_event(), bytes, flops};
-    HIP_CHECK(hipEventRecord(r.a, g_rt.stream));
     slot = (int)g_prof_pending.size();
     g_prof_pending.push_back(r);
+    g_cur_start = r.a;   // consumed by the launch inside this scope (one launch per scope)
+    g_cur_stop = r.b;
 }
 ProfScope::~ProfScope() {
     if (slot < 0) return;
-    HIP_CHECK(hipEventRecord(g_prof_pending[slot].b, g_rt.stream));
+    g_cur_start = g_cur_stop = nullptr;
 }
 
 static void prof_drain() {
@@ -227,31 +235,6 @@ void nvllm_prof_reset(void) {
         g_prof_launches[i] = 0;
         g_prof_ms[i] = g_prof_bytes[i] = g_prof_flops[i] = 0.0;
     }
-}
-// Elapsed time of an event pair with nothing between the two records: what the
-// bracket itself adds to every timed launch (packet processing on either side).
-double nvllm_prof_event_overhead_ms(void) {
-    ensure_init();
-    const int n = 64;
-    hipEvent_t a[n], b[n];
-    for (int i = 0; i < n; i++) {
-        a[i] = prof_event();
-        b[i] = prof_event();
-    }
-    for (int i = 0; i < n; i++) {
-        HIP_CHECK(hipEventRecord(a[i], g_rt.stream));
-        HIP_CHECK(hipEventRecord(b[i], g_rt.stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
-    double tot = 0.0;
-    for (int i = 0; i < n; i++) {
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, a[i], b[i]));
-        tot += ms;
-        g_prof_free.push_back(a[i]);
-        g_prof_free.push_back(b[i]);
-    }
-    return tot / n;
 }
 int nvllm_prof_num_classes(void) { return PC_COUNT; }
 const char* nvllm_prof_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
