@@ -131,6 +131,46 @@ def test_batch_of_64_sequences_matches_the_oracle(hip, oracle, tmp_models, kv_by
     assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), worst
 
 
+def _random_shapes(n, seed):
+    """Random small Llama shapes inside what the reference and the library both accept:
+    widths that are multiples of 32, head_dim in the supported set, GQA ratios 1..8,
+    vocabularies that are not multiples of the kernel's tile width."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    while len(out) < n:
+        hd = int(r.choice([16, 32, 48, 64, 96, 128]))
+        kvh = int(r.choice([1, 2, 3, 4]))
+        group = int(r.choice([1, 2, 4, 8]))
+        heads = kvh * group
+        dim = heads * hd
+        if dim % 32 or dim > 768 or (kvh * hd) % 16:
+            continue
+        out.append(dict(dim=dim, hidden_dim=int(r.integers(2, 12)) * 32, n_layers=int(r.integers(1, 4)), n_heads=heads,
+                        n_kv_heads=kvh, vocab_size=int(r.integers(200, 900)), max_seq_len=160))
+    return out
+
+
+@pytest.mark.parametrize("idx,shape_kw", list(enumerate(_random_shapes(10, 2024))))
+def test_random_shapes_mixed_batches(hip, oracle, tmp_models, idx, shape_kw):
+    """Whole runs (chunked prefill + decode, staggered arrivals) on randomly drawn model
+    shapes, fp32 rows for even draws and fp16 pages for odd ones."""
+    path, shape = tmp_models("tiny", seed=30 + idx, **shape_kw)
+    n_seqs = 2 + idx % 5
+    prompts = synth.make_requests(n_seqs, 2, 60, shape.vocab_size, seed=40 + idx)
+    kw = dict(n_new=14, arrivals=[(3 * i) % 5 for i in range(n_seqs)], collect_logits=True,
+              chunk_size=[5, 16, 33, 1000][idx % 4], temperature=0.0, max_steps=500)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    kv_bytes = 2 if idx % 2 else 4
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(kv_bytes)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare_runs(g, o)
+    assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), (shape_kw, worst)
+
+
 def test_argmax_only_mode_matches_host_logits_mode(hip, tmp_models):
     path, shape = tmp_models("tiny")
     prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=6)
