@@ -77,7 +77,7 @@ __device__ __forceinline__ void store_a16_8(__half* a16, int t, int k, int Kb, c
 // ---------------------------------------------------------------- embedding
 // Embedding gather fused with the first layer's input preparation: fp32 residual
 // row, the row times the first RMSNorm gain as fp16 hi/lo tiles, and the sum of
-// squares per 64-feature tile (the consumer projection turns those into 1/rms).
+// squares per 32-feature group (the consumer projection turns those into 1/rms).
 __global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, __half* __restrict__ a16,
                                                         float* __restrict__ ss, const __half* __restrict__ table,
                                                         const int* __restrict__ tokens,
@@ -100,11 +100,10 @@ __global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, _
             *reinterpret_cast<float4*>(dst + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
             store_a16_8(a16, t, i, Kb, y);
         }
-        // 8 consecutive threads cover one 64-feature tile
+        // 4 consecutive threads cover one 32-feature group
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
-        part += __shfl_xor(part, 4, 64);
-        if ((threadIdx.x & 7) == 0 && (i >> 6) < ss_tiles) ss[(size_t)t * ss_tiles + (i >> 6)] = part;
+        if ((threadIdx.x & 3) == 0 && (i >> 5) < ss_tiles) ss[(size_t)t * ss_tiles + (i >> 5)] = part;
     }
 }
 
@@ -114,7 +113,7 @@ void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table
     if (D % 32) NVLLM_FATAL("embedding width %d is not a multiple of 32", D);
     ProfScope ps(PC_EMBED, (double)T * D * 10, 0);
     NVLLM_LAUNCH(k_embed_prescale, dim3(T), dim3(256), 0, x, a16, ss, table, tokens, gain, D,
-                       cdiv(D, 64));
+                       cdiv(D, 32));
 }
 
 // Compact the rows that produce logits: tile-order rows idx[r] -> rows r.

@@ -323,9 +323,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- 3. epilogue on complete sums
-    float ssq[IPT];
+    float ssq[ROUNDS][IPT];
 #pragma unroll
-    for (int q = 0; q < IPT; q++) ssq[q] = 0.f;
+    for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+        for (int q = 0; q < IPT; q++) ssq[h][q] = 0.f;
 #pragma unroll
     for (int h = 0; h < ROUNDS; h++) {
         if (EPI == GemmEpilogue::SWIGLU_A16) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                     *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
                     const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
                     store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
-                    ssq[q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
+                    ssq[h][q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
                 }
             } else {  // ROPE_KV
                 if (live) {
@@ -417,20 +419,26 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         }
     }
     if (EPI == GemmEpilogue::RESID_A16) {
-        // per-token sum of x^2 over this tile's 64 features: over the 4 lane groups
-        // (l>>4), then over i (two halves of the workgroup)
+        // per-token sum of x^2 over each 32-feature group (= one round: two row blocks):
+        // over the 4 lane groups (l>>4), then over the round's two row blocks (i)
+        const int ss_cols = (p.N + 31) >> 5;
 #pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            float s = ssq[q];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            const int e = threadIdx.x + q * NW * 64;
-            if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < TB * 16) {
-            const int t = tb0 * 16 + threadIdx.x;
-            if (t < p.T) ep.ss_out[(size_t)t * gridDim.x + blockIdx.x] = s_ss[0][threadIdx.x] + s_ss[1][threadIdx.x];
+        for (int h = 0; h < ROUNDS; h++) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                float sq = ssq[h][q];
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const int e = threadIdx.x + q * NW * 64;
+                if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
+            }
+            __syncthreads();
+            if (threadIdx.x < TB * 16) {
+                const int t = tb0 * 16 + threadIdx.x;
+                const int col = blockIdx.x * ROUNDS + h;
+                if (t < p.T && col < ss_cols) ep.ss_out[(size_t)t * ss_cols + col] = s_ss[0][threadIdx.x] + s_ss[1][threadIdx.x];
+            }
         }
     }
 }
@@ -439,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
 constexpr int GEMM_NBW = 4;
 constexpr int GEMM_NW = 8;
 
-int gemm_feature_tiles(int N) { return cdiv(cdiv(N, 16), GEMM_NBW); }
+int gemm_feature_tiles(int N) { return cdiv(N, 32); }
 
 int gemm_pick_ksplit(int N, int K, int T) {
     const int NB = cdiv(N, 16), Kb = cdiv(K, 32);
@@ -457,21 +465,21 @@ int gemm_pick_ksplit(int N, int K, int T) {
 static unsigned* g_counters = nullptr;
 constexpr int MAX_COUNTERS = 1 << 16;
 
-template <int TB, typename KVT>
+template <int NBW, int TB, typename KVT>
 static void launch_tb(const GemmArgs& a, dim3 grid) {
     const dim3 block(GEMM_NW * 64);
     switch (a.e.kind) {
         case GemmEpilogue::F32:
-            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, a);
+            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, a);
             break;
         case GemmEpilogue::SWIGLU_A16:
-            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, a);
+            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, a);
             break;
         case GemmEpilogue::RESID_A16:
-            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, a);
+            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, a);
             break;
         default:
-            NVLLM_LAUNCH((k_gemm<GEMM_NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, a);
+            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, a);
             break;
     }
 }
@@ -494,9 +502,24 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     a.N = N;
     a.T = T;
     a.e = epi;
-    const int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
-    const int tiles_n = cdiv(a.NB, GEMM_NBW), tiles_t = cdiv(a.Tb, TB);
+    int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
+    int nbw = GEMM_NBW;
     int ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, w.K, T);
+    // Narrow projections with a short K (wo, qkv at decode): instead of cutting K across
+    // workgroups -- whose partial sums then meet through memory, a chain of dependent
+    // round trips -- cut the TOKENS: 32-feature tiles x 16-token groups, every workgroup
+    // sweeps the whole K and finishes its own outputs.  The weight tile is read by the
+    // token groups' workgroups (one read from HBM, the rest from cache); worth it while a
+    // full sweep is short.
+    static const int tsplit_env = getenv("NVLLM_GEMM_TSPLIT") ? atoi(getenv("NVLLM_GEMM_TSPLIT")) : 1;
+    const bool tsplit = tsplit_env && force_ksplit <= 0 && ks > 1 && TB > 1 && a.Kb <= 64 && a.Tb <= 8 &&
+                        epi.kind != GemmEpilogue::SWIGLU_A16;
+    if (tsplit) {
+        TB = 1;
+        nbw = 2;
+        ks = 1;
+    }
+    const int tiles_n = cdiv(a.NB, nbw), tiles_t = cdiv(a.Tb, TB);
     if ((long)tiles_n * tiles_t > MAX_COUNTERS) ks = 1;
     a.kb_per_split = cdiv(a.Kb, ks);
     ks = cdiv(a.Kb, a.kb_per_split);
@@ -504,7 +527,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     a.counters = g_counters;
     a.slab = nullptr;
     if (ks > 1) {
-        const size_t tile_bytes = (size_t)(GEMM_NBW / 2) * 2 * TB * 64 * 16;
+        const size_t tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
         a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles_n * tiles_t * ks * tile_bytes);
     }
     if (epi.kind == GemmEpilogue::SWIGLU_A16) {
@@ -521,14 +544,17 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 + out_bytes;
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
-    if (kv16) {
-        if (TB == 1) launch_tb<1, __half>(a, grid);
-        else if (TB == 2) launch_tb<2, __half>(a, grid);
-        else launch_tb<4, __half>(a, grid);
+    if (nbw == 2) {   // token-split configuration
+        if (kv16) launch_tb<2, 1, __half>(a, grid);
+        else launch_tb<2, 1, float>(a, grid);
+    } else if (kv16) {
+        if (TB == 1) launch_tb<GEMM_NBW, 1, __half>(a, grid);
+        else if (TB == 2) launch_tb<GEMM_NBW, 2, __half>(a, grid);
+        else launch_tb<GEMM_NBW, 4, __half>(a, grid);
     } else {
-        if (TB == 1) launch_tb<1, float>(a, grid);
-        else if (TB == 2) launch_tb<2, float>(a, grid);
-        else launch_tb<4, float>(a, grid);
+        if (TB == 1) launch_tb<GEMM_NBW, 1, float>(a, grid);
+        else if (TB == 2) launch_tb<GEMM_NBW, 2, float>(a, grid);
+        else launch_tb<GEMM_NBW, 4, float>(a, grid);
     }
     return ks;
 }

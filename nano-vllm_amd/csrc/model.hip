@@ -296,7 +296,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     const float2* rope = rope_table(p->rope_theta, hd, st.max_pos + 1);
     const KvPoolView pool = pool_view(&g_kv_manager, KVH, hd);
 
-    const int ssn = gemm_feature_tiles(D);   // 64-feature tiles of the residual width
+    const int ssn = gemm_feature_tiles(D);   // 32-feature groups of the residual width
     __half* a16_x = (__half*)ws_get(WS_A16_X, a16_halves(T, D) * sizeof(__half));
     __half* a16_att = (__half*)ws_get(WS_A16_ATT, a16_halves(T, QD) * sizeof(__half));
     __half* a16_h = (__half*)ws_get(WS_A16_H, a16_halves(T, F) * sizeof(__half));

@@ -180,7 +180,7 @@ struct GemmEpilogue {
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
                 const GemmEpilogue& epi, int force_ksplit, int prof_cls);
 int gemm_pick_ksplit(int N, int K, int T);
-int gemm_feature_tiles(int N);   // 64-feature tiles of a projection output = columns of ss_out
+int gemm_feature_tiles(int N);   // 32-feature groups of a projection output = columns of ss_out
 void gemm_release();
 
 void launch_pack_a16(__half* a16, const float* in, int T, int K);
@@ -245,7 +245,7 @@ struct AttnArgs {
 void launch_paged_attention(const AttnArgs& a);
 int attn_tokens_per_item(int H, int KVH);
 
-// x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 64j..64j+63
+// x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 32j..32j+31
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
                            const float* gain, int T, int D);
 // rows idx[r] of an a16 activation (and of its ss table) compacted to rows r = 0..B-1
