@@ -515,7 +515,10 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     const bool tsplit = tsplit_env && force_ksplit <= 0 && ks > 1 && TB > 1 && a.Kb <= 64 && a.Tb <= 8 &&
                         epi.kind != GemmEpilogue::SWIGLU_A16;
     if (tsplit) {
-        TB = 1;
+        // 16-token groups unless that makes more workgroups than CUs (a CU with two of
+        // them takes twice as long: measured 12.3 us against 10.0 for qkv); then 32-token groups
+        const bool wide = cdiv(a.NB, 2) * a.Tb > rt().num_cus;
+        TB = wide ? 2 : 1;
         nbw = 2;
         ks = 1;
     }
@@ -545,8 +548,8 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
     if (nbw == 2) {   // token-split configuration
-        if (kv16) launch_tb<2, 1, __half>(a, grid);
-        else launch_tb<2, 1, float>(a, grid);
+        if (kv16) { if (TB == 1) launch_tb<2, 1, __half>(a, grid); else launch_tb<2, 2, __half>(a, grid); }
+        else { if (TB == 1) launch_tb<2, 1, float>(a, grid); else launch_tb<2, 2, float>(a, grid); }
     } else if (kv16) {
         if (TB == 1) launch_tb<GEMM_NBW, 1, __half>(a, grid);
         else if (TB == 2) launch_tb<GEMM_NBW, 2, __half>(a, grid);
