@@ -122,6 +122,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * NBW;
+    if (nb0 >= p.NB) return;   // grid padded for XCD alignment
     const int kb_begin = blockIdx.y * p.kb_per_split;
     const int kb_end = min(p.Kb, kb_begin + p.kb_per_split);
     const int tb0 = blockIdx.z * TB;
@@ -530,7 +531,22 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         TB = 2;
         ks /= 2;
     }
-    const int tiles_n = cdiv(a.NB, nbw), tiles_t = cdiv(a.Tb, TB);
+    // The wide gate/up projection at full decode width: 64 x 64 tiles give 176 workgroups
+    // (80 CUs idle) pulling 768 KiB each; 96-feature x 32-token tiles give 236 workgroups
+    // pulling 640 KiB each, still in one wave of workgroups.
+    static const int gu_env = getenv("NVLLM_GEMM_GU96") ? atoi(getenv("NVLLM_GEMM_GU96")) : 1;
+    const bool gu96 = gu_env && !tsplit && force_ksplit <= 0 && epi.kind == GemmEpilogue::SWIGLU_A16 && ks == 1 &&
+                      a.Tb > 2 && a.Tb <= 4 && cdiv(a.NB, 6) * 2 <= rt().num_cus && cdiv(a.NB, 4) < rt().num_cus;
+    if (gu96) {
+        TB = 2;
+        nbw = 6;
+    }
+    int tiles_n = cdiv(a.NB, nbw);
+    const int tiles_t = cdiv(a.Tb, TB);
+    // Token groups of one tile read the same weights: with workgroups dealt round-robin to
+    // the 8 XCDs, a grid width that is a multiple of 8 puts them behind the same L2 (speed
+    // only; surplus workgroups exit at once).
+    if (tiles_t > 1 && ks == 1) tiles_n = (tiles_n + 7) & ~7;
     if ((long)tiles_n * tiles_t > MAX_COUNTERS) ks = 1;
     a.kb_per_split = cdiv(a.Kb, ks);
     ks = cdiv(a.Kb, a.kb_per_split);
@@ -555,7 +571,9 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 + out_bytes;
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
-    if (nbw == 2) {   // token-split configuration
+    if (nbw == 6) {
+        NVLLM_LAUNCH((k_gemm<6, 2, GEMM_NW, GemmEpilogue::SWIGLU_A16, float>), grid, dim3(GEMM_NW * 64), 0, a);
+    } else if (nbw == 2) {   // token-split configuration
         if (kv16) { if (TB == 1) launch_tb<2, 1, __half>(a, grid); else launch_tb<2, 2, __half>(a, grid); }
         else { if (TB == 1) launch_tb<2, 1, float>(a, grid); else launch_tb<2, 2, float>(a, grid); }
     } else if (kv16) {
