@@ -353,9 +353,12 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
 
     u2_t kr[PF][NC], vr[PF][NC];
     const int voff = lane * 8;
-    auto issue = [&](int slot, int pg) {
+    // block id of a page of this wave (a scalar load); looked up one ring turn before the
+    // page is requested, so that the request never waits for the table
+    auto blk_of = [&](int pg) -> int { return table[pg < pg_end ? pg : 0]; };
+    auto issue = [&](int slot, int pg, int blk) {
         const bool ok = pg < pg_end;   // wave-uniform
-        const long block = table[ok ? pg : 0];
+        const long block = blk;
         const long off = kv16_page(block, kvh, a.KVH, HD);
         const int bytes = ok ? 32 * HD : 0;
         auto rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pk + off), 0, bytes, 0x00020000);
@@ -423,14 +426,18 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     // ---- page loop: PF pages in flight per wave
 #pragma unroll
     for (int s = 0; s < PF; s++) {
-        issue(s, pg_begin + 4 * s);
+        issue(s, pg_begin + 4 * s, blk_of(pg_begin + 4 * s));
         __builtin_amdgcn_sched_barrier(0);   // keep issue order = consumption order (counted vmcnt waits)
     }
+    int nblk[PF];
+#pragma unroll
+    for (int s = 0; s < PF; s++) nblk[s] = blk_of(pg_begin + 4 * (s + PF));
     for (int pg = pg_begin; pg < pg_end; pg += 4 * PF) {
 #pragma unroll
         for (int s = 0; s < PF; s++) {
             if (pg + 4 * s < pg_end) compute(s, pg + 4 * s);
-            issue(s, pg + 4 * (s + PF));
+            issue(s, pg + 4 * (s + PF), nblk[s]);
+            nblk[s] = blk_of(pg + 4 * (s + 2 * PF));
         }
     }
 
