@@ -576,6 +576,10 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     } else if (nbw == 2) {   // token-split configuration
         if (kv16) { if (TB == 1) launch_tb<2, 1, __half>(a, grid); else launch_tb<2, 2, __half>(a, grid); }
         else { if (TB == 1) launch_tb<2, 1, float>(a, grid); else launch_tb<2, 2, float>(a, grid); }
+    } else if (epi.kind == GemmEpilogue::F32 && TB == 4 && ks == 1 && (long)tiles_n * tiles_t > rt().num_cus) {
+        // more tiles than CUs (the classifier): four waves per workgroup, so that two
+        // workgroups share a CU and one's start-up overlaps the other's streaming (41 -> 35.5 us)
+        NVLLM_LAUNCH((k_gemm<GEMM_NBW, 4, 4, GemmEpilogue::F32, float>), grid, dim3(4 * 64), 0, a);
     } else if (kv16) {
         if (TB == 1) launch_tb<GEMM_NBW, 1, __half>(a, grid);
         else if (TB == 2) launch_tb<GEMM_NBW, 2, __half>(a, grid);
