@@ -392,12 +392,36 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
     const float* row = logits + (size_t)blockIdx.x * V;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float v = row[i];
+    auto take = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) {
             best = v;
             bi = i;
         }
+    };
+    if ((V & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        // 16-byte loads, eight in flight per thread before the first compare
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        const int n4 = V >> 2;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * blockDim.x) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * blockDim.x;
+                v[u] = r4[i < n4 ? i : n4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + u * blockDim.x;
+                if (i < n4) {
+                    take(v[u].x, 4 * i);
+                    take(v[u].y, 4 * i + 1);
+                    take(v[u].z, 4 * i + 2);
+                    take(v[u].w, 4 * i + 3);
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < V; i += blockDim.x) take(row[i], i);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
