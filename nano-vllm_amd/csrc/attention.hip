@@ -1,16 +1,18 @@
 // attention.hip -- causal attention of a ragged batch over the block pool
 // (reference src/kernels/attention.c:256-336 and its single-sequence / contiguous
-// siblings) in exact fp32 on the matrix cores.
+// siblings) on the matrix cores, in two variants selected by the pool's format.
 //
-// K and V are streamed from HBM exactly once per (sequence, kv head) and go
-// straight from global memory into v_mfma_f32_16x16x4_f32 operands -- no LDS, no
-// cross-lane broadcast.  One WAVE owns one work item:
+// Common to both: K and V are streamed from HBM exactly once per (sequence, kv head)
+// and go straight from global memory into MFMA operands -- no LDS staging, no
+// cross-lane broadcast.  A work item is
 //     (run of up to CT consecutive tokens of one sequence) x (group of GT query
-//     heads sharing a KV head) x (slice of the key pages),   CT * GT = 16.
+//     heads sharing a KV head) [x (slice of the key pages)],   CT * GT = 16;
+// the host describes the runs (first token, count, last position, block-table offset).
 // The 16 (token, head) pairs are the 16 "columns" of every MFMA; a decode token
 // fills GT of them, a prefill chunk all 16, so prefill re-reads K/V CT times less.
 //
-// Per page (16 keys, the pool's block size -- one page is 16 consecutive rows):
+// fp32 pool (the reference's rows), k_paged_attn: one WAVE per item and key slice,
+// exact fp32 on v_mfma_f32_16x16x4_f32.  Per page (16 keys = the pool's block size):
 //   S^T[key, col] = sum_d K[key, d] * Q[col, d]      A = K (lane: key = l&15, 4 dims
 //                                                     chosen by l>>4), B = Q^T
 //       -> lane (col = l&15, g = l>>4) holds the scores of keys 4g..4g+3 of ITS column,
@@ -21,6 +23,8 @@
 // fp32 MFMA is an exact fma chain, so the arithmetic is fp32 throughout like the
 // reference; only the summation order differs.  Key slices of one column leave
 // (acc, max, sum) partials that k_attn_combine merges.
+//
+// fp16 pool (pages in operand order), k_paged_attn16: see the comment above it.
 #include "nvllm_internal.h"
 
 namespace nvllm {

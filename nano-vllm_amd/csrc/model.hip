@@ -328,9 +328,6 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         at.out_a16 = a16_att;
         at.pool = pool;
         at.layer = l;
-        at.pos = st.d_pos;
-        at.seq = st.d_seq;
-        at.tbl_off = st.d_tbl_off;
         at.tables = st.d_tables;
         at.T = T; at.H = H; at.KVH = KVH; at.hd = hd;
         at.max_pos = st.max_pos;

@@ -231,10 +231,6 @@ struct AttnArgs {
     __half* out_a16;       // tiles of [T, H*hd] or null
     KvPoolView pool;
     int layer;
-    const int* pos;        // device [T] (null: pos0 + t)
-    int pos0;
-    const int* seq;        // device [T] (null: single table at tbl_off 0)
-    const int* tbl_off;    // device [n_seqs]
     const int* tables;     // device, concatenated block tables (null: contiguous cache)
     int T, H, KVH, hd;
     int max_pos;           // largest position in the batch (host knowledge, for split sizing)

@@ -317,7 +317,6 @@ void multi_head_attention(float* out, float* q, float* key_cache, float* value_c
     a.out_f32 = out;
     a.pool = contiguous_view(key_cache, value_cache, max_seq_len, n_kv_heads, head_dim);
     a.layer = layer;
-    a.pos0 = pos;
     a.T = num_tokens;
     a.H = n_heads;
     a.KVH = n_kv_heads;
@@ -343,8 +342,6 @@ void paged_attention(float* out, float* q, KVCacheManager* mgr, BlockTable* bloc
     a.out_f32 = out;
     a.pool = pool_view(mgr, n_kv_heads, head_dim);
     a.layer = layer;
-    a.pos0 = pos;
-    a.tbl_off = s.d_tbl_off;
     a.tables = s.d_tables;
     a.T = num_tokens;
     a.H = n_heads;
@@ -371,9 +368,6 @@ void paged_attention_batch(float* out, float* q, KVCacheManager* mgr, BlockTable
     a.out_f32 = out;
     a.pool = pool_view(mgr, n_kv_heads, head_dim);
     a.layer = layer;
-    a.pos = s.d_pos;
-    a.seq = s.d_seq;
-    a.tbl_off = s.d_tbl_off;
     a.tables = s.d_tables;
     a.T = num_tokens;
     a.H = n_heads;
