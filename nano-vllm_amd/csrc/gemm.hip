@@ -4,14 +4,19 @@
 // that follows each projection fused into its epilogue.
 //
 // Shape of the problem at decode: T <= 64 tokens, so every weight byte is used
-// for only 2*T flops and the kernel is bound by how fast the weights stream.
-// Work decomposition (one launch per projection):
-//   grid.x  tiles of NBW 16-row blocks of W (64 output features)
-//   grid.y  split of K across workgroups, used where the grid would otherwise be
-//           too small to keep every CU streaming
-//   grid.z  groups of TB*16 tokens (prefill: weights re-read from L2/MALL)
+// for only 2*T flops and the kernel is bound by how fast bytes reach the CUs.
+// One kernel template, instantiated per tile shape (one launch per projection):
+//   grid.x  tiles of NBW 16-row blocks of W
+//   grid.y  split of K across workgroups (the last resort: its partial sums meet
+//           through memory, a chain of dependent round trips)
+//   grid.z  groups of TB*16 tokens
 //   inside a workgroup the NW waves take the K-steps round-robin, each with all
 //   NBW row blocks, and their accumulators are summed through LDS at the end.
+// launch_gemm() picks (NBW, TB, K split) per projection so that one wave of
+// workgroups covers the chip: token groups instead of K slices for short-K narrow
+// projections, 96 x 32 tiles for the wide one, 64-feature tiles x 32-token groups x
+// a shallow K split for long K; grids with token groups are padded to a multiple of 8
+// so that the groups of one weight tile run behind the same XCD's L2.
 // Per K-step (32 k) a wave loads NBW weight tiles (1 KiB each, one fully
 // coalesced dwordx4 per lane, non-temporal) and 2*TB activation tiles (L2), and
 // issues 2*NBW*TB v_mfma_f32_16x16x32_f16.  Weight loads run RW steps ahead,
@@ -26,7 +31,7 @@
 //   F32         logits (scaled by the token's 1/rms)
 //   SWIGLU_A16  silu(gate) * up             -> fp16 hi/lo tiles for w_down
 //   RESID_A16   x += result; x * next_gain  -> tiles for the next projection,
-//               plus per-tile sums of x^2 from which the consumer forms 1/rms
+//               plus sums of x^2 per 32 features from which the consumer forms 1/rms
 //   ROPE_KV     rotate q,k; q -> fp32 rows for attention; k,v -> block pool
 // RMSNorm is thereby split in two: the producer stores x*g (no reduction needed),
 // the consumer multiplies its result by 1/rms (a per-token scalar commutes with
