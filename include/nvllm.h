@@ -8,6 +8,8 @@
 #ifndef NVLLM_H
 #define NVLLM_H
 
+#include <stddef.h>
+
 #include "structs.h"
 
 #ifdef __cplusplus
@@ -63,6 +65,45 @@ const char* nvllm_prof_name(int cls);
  * (what the kernel must read+write at least once) and flops.  Resolves pending
  * events (synchronises the stream). */
 void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* bytes, double* flops);
+
+/* ------------------------------------------------------- tensor parallelism */
+/* No counterpart in the reference, which is one process on one device.  The forward
+ * pass of ONE model is split over `world` processes (one per GPU): each keeps
+ * n_heads/world attention heads (whole kv heads with their query heads) and
+ * hidden_dim/world columns of the MLP, and the partial results of the two projections
+ * that return to the residual width are summed over the ranks -- after the wo
+ * projection (src/model.c:385) and after w_down (src/model.c:392).  All ranks must
+ * issue identical calls with identical arguments (same model file, requests, block
+ * tables); Config, RunState and the block tables keep their full-model meaning, the
+ * weight handles in `Weights` and the KV pool cover this rank's slice only.
+ * Set up before load_model() and init_kv_cache_manager(). */
+typedef struct {
+    int rank, world;
+    int n_heads, head0;        /* query heads of this rank: [head0, head0 + n_heads)        */
+    int n_kv_heads, kv_head0;  /* kv heads of this rank                                     */
+    int hidden, hidden0;       /* columns of the hidden activation: [hidden0, hidden0+hidden) */
+} NvllmTpShard;
+/* The slice rank `rank` of `world` owns for this model shape.  0, or -1 when the shape
+ * does not divide (kv heads and heads by world, hidden_dim by 32*world). */
+int nvllm_tp_shard(const Config* cfg, int rank, int world, NvllmTpShard* out);
+
+/* RCCL over xGMI.  One rank obtains an id and hands it to the others by whatever means
+ * the host has (a file, a socket, torch.distributed); then every rank calls
+ * nvllm_tp_init with the same id.  The all-reduces run on nvllm_stream(). */
+#define NVLLM_TP_ID_BYTES 128
+int nvllm_tp_unique_id(void* id /* NVLLM_TP_ID_BYTES */);
+int nvllm_tp_init(int rank, int world, const void* id);
+
+/* The same with the exchange supplied by the caller: fn must leave the element-wise sum
+ * over all ranks of the `count` floats at device_buf in device_buf on every rank,
+ * ordered after the work already enqueued on hip_stream and before work enqueued
+ * later (enqueue on that stream, or synchronise it). */
+typedef void (*nvllm_allreduce_fn)(void* ctx, float* device_buf, size_t count, void* hip_stream);
+int nvllm_tp_init_custom(int rank, int world, nvllm_allreduce_fn fn, void* ctx);
+
+void nvllm_tp_finalize(void);
+int  nvllm_tp_rank(void);
+int  nvllm_tp_world(void);
 
 /* ------------------------------------------------------ N-sequence driver */
 /* The reference's scheduler with the sequence count as a parameter: arrival

@@ -57,6 +57,15 @@ class Sampler(C.Structure):
                 ("probindex", C.POINTER(ProbIndex)), ("vocab_size", C.c_int)]
 
 
+class TpShard(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("rank", "world", "n_heads", "head0", "n_kv_heads", "kv_head0", "hidden", "hidden0")]
+
+
+# void fn(void* ctx, float* device_buf, size_t count, void* hip_stream)
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+TP_ID_BYTES = 128
+
+
 class EngineOptions(C.Structure):
     _fields_ = [("chunk_size", C.c_int), ("block_size", C.c_int), ("num_blocks", C.c_int),
                 ("max_seq_len", C.c_int), ("raise_to_1024", C.c_int), ("recycle_blocks", C.c_int),
@@ -150,6 +159,13 @@ _HIP_ONLY = {
     "nvllm_prof_get": (_V, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nvllm_free_model": (_V, [C.POINTER(Weights)]),
+    "nvllm_tp_shard": (_I, [C.POINTER(Config), _I, _I, C.POINTER(TpShard)]),
+    "nvllm_tp_unique_id": (_I, [_P]),
+    "nvllm_tp_init": (_I, [_I, _I, _P]),
+    "nvllm_tp_init_custom": (_I, [_I, _I, ALLREDUCE_FN, _P]),
+    "nvllm_tp_finalize": (_V, []),
+    "nvllm_tp_rank": (_I, []),
+    "nvllm_tp_world": (_I, []),
 }
 
 DEVICE_TO_HOST, DEVICE_TO_DEVICE, HOST_TO_DEVICE = 0, 1, 2

@@ -116,6 +116,45 @@ void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table
                        cdiv(D, 32));
 }
 
+// Residual add + preparation of the next projection's input, for a projection whose
+// output y was completed outside its own kernel (summed over tensor-parallel ranks):
+// the same arithmetic as the fused epilogue of the projection kernel.
+__global__ __launch_bounds__(256) void k_resid_prescale(float* __restrict__ x, const float* __restrict__ y,
+                                                        __half* __restrict__ a16, float* __restrict__ ss,
+                                                        const float* __restrict__ gain, int D, int ss_tiles) {
+    const int t = blockIdx.x;
+    float* xr = x + (size_t)t * D;
+    const float* yr = y + (size_t)t * D;
+    const int Kb = (D + 31) >> 5;
+    for (int i = threadIdx.x * 8; i < ((D + 63) & ~63); i += blockDim.x * 8) {
+        float v[8], g[8], part = 0.f;
+        if (i < D) {   // D % 8 == 0
+            const float4 a0 = *reinterpret_cast<const float4*>(xr + i), a1 = *reinterpret_cast<const float4*>(xr + i + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(yr + i), b1 = *reinterpret_cast<const float4*>(yr + i + 4);
+            v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
+            v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                g[j] = v[j] * gain[i + j];
+                part += v[j] * v[j];
+            }
+            *reinterpret_cast<float4*>(xr + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(xr + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            store_a16_8(a16, t, i, Kb, g);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if ((threadIdx.x & 3) == 0 && (i >> 5) < ss_tiles) ss[(size_t)t * ss_tiles + (i >> 5)] = part;
+    }
+}
+
+void launch_resid_prescale(float* x, const float* y, __half* a16, float* ss, const float* gain, int T, int D) {
+    if (T <= 0) return;
+    if (D % 32) NVLLM_FATAL("residual width %d is not a multiple of 32", D);
+    ProfScope ps(PC_ELEMWISE, (double)T * D * 16, 0);
+    NVLLM_LAUNCH(k_resid_prescale, dim3(T), dim3(256), 0, x, y, a16, ss, gain, D, cdiv(D, 32));
+}
+
 // Compact the rows that produce logits: tile-order rows idx[r] -> rows r.
 __global__ __launch_bounds__(256) void k_gather_a16(__half* __restrict__ dst, float* __restrict__ dst_ss,
                                                     const __half* __restrict__ src,

@@ -29,6 +29,7 @@ struct LayerPriv {
 
 struct ModelPriv {
     Config cfg;
+    NvllmTpShard sh;   // the slice of heads / hidden columns held here (everything when world == 1)
     void* arena = nullptr;
     size_t arena_bytes = 0;
     const __half* embed = nullptr;   // [V, D] row-major fp16
@@ -102,15 +103,25 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
         exit(1);
     }
     if (fp32) printf("nvllm: fp32 checkpoint: matrices are rounded to fp16 for HBM residency\n");
+    // tensor parallelism: this process keeps the heads / hidden columns of its rank
+    NvllmTpShard sh;
+    if (nvllm_tp_shard(p, tp().rank, tp().world, &sh) != 0) {
+        fprintf(stderr, "model shape (heads %d/%d, hidden %d) does not divide over %d tensor-parallel ranks\n",
+                p->n_heads, p->n_kv_heads, p->hidden_dim, tp().world);
+        exit(1);
+    }
+    const long long QDl = (long long)sh.n_heads * p->head_dim, KDl = (long long)sh.n_kv_heads * p->head_dim, Fl = sh.hidden;
+    const long long q0 = (long long)sh.head0 * p->head_dim, k0 = (long long)sh.kv_head0 * p->head_dim, f0 = sh.hidden0;
 
     ModelPriv* m = new ModelPriv();
     m->cfg = *p;
+    m->sh = sh;
     // ---- arena plan (all offsets 256-byte aligned)
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t Kb_D = D / 32, Kb_QD = QD / 32, Kb_F = F / 32;
-    const size_t t_qkv = (size_t)((QD + 2 * KD) / 16) * Kb_D * TILE_HALVES * 2;
+    const size_t Kb_D = D / 32, Kb_QD = QDl / 32, Kb_F = Fl / 32;
+    const size_t t_qkv = (size_t)((QDl + 2 * KDl) / 16) * Kb_D * TILE_HALVES * 2;
     const size_t t_wo = (size_t)(D / 16) * Kb_QD * TILE_HALVES * 2;
-    const size_t t_gu = (size_t)(2 * F / 16) * Kb_D * TILE_HALVES * 2;
+    const size_t t_gu = (size_t)(2 * Fl / 16) * Kb_D * TILE_HALVES * 2;
     const size_t t_dn = (size_t)(D / 16) * Kb_F * TILE_HALVES * 2;
     const size_t t_head = (size_t)((V + 15) / 16) * Kb_D * TILE_HALVES * 2;
     const size_t per_layer = align(t_qkv) + align(t_wo) + align(t_gu) + align(t_dn) + 2 * align(D * 4);
@@ -155,6 +166,23 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
         if (fp32) launch_f32_to_f16(stage16, (const float*)stage, n);
         HIP_CHECK(hipStreamSynchronize(st));  // `host` is reused by the next tensor
     };
+    // rows [r0, r0 + nr) of a [rows, K] tensor: only that part of the file is read
+    auto fetch_rows = [&](size_t rows, size_t K, size_t r0, size_t nr, const char* what) {
+        if (r0 && fseek(f, (long)(r0 * K * esz), SEEK_CUR) != 0) NVLLM_FATAL("seek failed in %s", what);
+        read_exact(f, host, nr * K * esz, what);
+        if (rows > r0 + nr && fseek(f, (long)((rows - r0 - nr) * K * esz), SEEK_CUR) != 0) NVLLM_FATAL("seek failed in %s", what);
+        HIP_CHECK(hipMemcpyAsync(stage, host, nr * K * esz, hipMemcpyHostToDevice, st));
+        if (fp32) launch_f32_to_f16(stage16, (const float*)stage, nr * K);
+        HIP_CHECK(hipStreamSynchronize(st));
+    };
+    // columns [c0, c0 + nc) of a [rows, K] tensor, compacted to [rows, nc] by the upload
+    auto fetch_cols = [&](size_t rows, size_t K, size_t c0, size_t nc, const char* what) {
+        read_exact(f, host, rows * K * esz, what);
+        HIP_CHECK(hipMemcpy2DAsync(stage, nc * esz, (const char*)host + c0 * esz, K * esz, nc * esz, rows,
+                                   hipMemcpyHostToDevice, st));
+        if (fp32) launch_f32_to_f16(stage16, (const float*)stage, rows * nc);
+        HIP_CHECK(hipStreamSynchronize(st));
+    };
     auto fetch_vec = [&](const float* dst, size_t n, const char* what) {  // norm gains stay fp32
         read_exact(f, host, n * esz, what);
         HIP_CHECK(hipMemcpyAsync(stage, host, n * esz, hipMemcpyHostToDevice, st));
@@ -173,14 +201,14 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     if (shared) tile_into(m->head, V, D, str_D);
     HIP_CHECK(hipStreamSynchronize(st));
     for (int l = 0; l < L; l++) fetch_vec(m->layers[l].rms_att, D, "rms_att_weight");
-    for (int l = 0; l < L; l++) { fetch(D * QD, "wq"); tile_into(m->layers[l].qkv, QD, D, str_D); }
-    for (int l = 0; l < L; l++) { fetch(D * KD, "wk"); tile_into(m->layers[l].qkv + (QD / 16) * str_D, KD, D, str_D); }
-    for (int l = 0; l < L; l++) { fetch(D * KD, "wv"); tile_into(m->layers[l].qkv + ((QD + KD) / 16) * str_D, KD, D, str_D); }
-    for (int l = 0; l < L; l++) { fetch(QD * D, "wo"); tile_into(m->layers[l].wo, D, QD, str_QD); }
+    for (int l = 0; l < L; l++) { fetch_rows(QD, D, q0, QDl, "wq"); tile_into(m->layers[l].qkv, QDl, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch_rows(KD, D, k0, KDl, "wk"); tile_into(m->layers[l].qkv + (QDl / 16) * str_D, KDl, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch_rows(KD, D, k0, KDl, "wv"); tile_into(m->layers[l].qkv + ((QDl + KDl) / 16) * str_D, KDl, D, str_D); }
+    for (int l = 0; l < L; l++) { fetch_cols(D, QD, q0, QDl, "wo"); tile_into(m->layers[l].wo, D, QDl, str_QD); }
     for (int l = 0; l < L; l++) fetch_vec(m->layers[l].rms_ffn, D, "rms_ffn_weight");
-    for (int l = 0; l < L; l++) { fetch(D * F, "w_gate"); tile_into(m->layers[l].gateup, F, D, 2 * str_D); }
-    for (int l = 0; l < L; l++) { fetch(F * D, "w_down"); tile_into(m->layers[l].down, D, F, str_F); }  // file order: down before up (model.c:262-269)
-    for (int l = 0; l < L; l++) { fetch(D * F, "w_up"); tile_into(m->layers[l].gateup + str_D, F, D, 2 * str_D); }
+    for (int l = 0; l < L; l++) { fetch_rows(F, D, f0, Fl, "w_gate"); tile_into(m->layers[l].gateup, Fl, D, 2 * str_D); }
+    for (int l = 0; l < L; l++) { fetch_cols(D, F, f0, Fl, "w_down"); tile_into(m->layers[l].down, D, Fl, str_F); }  // file order: down before up (model.c:262-269)
+    for (int l = 0; l < L; l++) { fetch_rows(F, D, f0, Fl, "w_up"); tile_into(m->layers[l].gateup + str_D, Fl, D, 2 * str_D); }
     fetch_vec(m->rms_final, D, "rms_final_weight");
     if (!shared) { fetch(V * D, "lm_head"); tile_into(m->head, V, D, str_D); }
     fclose(f);
@@ -200,14 +228,14 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
         LayerPriv& lp = m->layers[l];
         LayerWeights& lw = w->layers[l];
         lw.rms_att_weight = (float*)lp.rms_att;
-        lw.wq = reg(lp.qkv, QD, D, str_D);
-        lw.wk = reg(lp.qkv + (QD / 16) * str_D, KD, D, str_D);
-        lw.wv = reg(lp.qkv + ((QD + KD) / 16) * str_D, KD, D, str_D);
-        lw.wo = reg(lp.wo, D, QD, str_QD);
+        lw.wq = reg(lp.qkv, QDl, D, str_D);
+        lw.wk = reg(lp.qkv + (QDl / 16) * str_D, KDl, D, str_D);
+        lw.wv = reg(lp.qkv + ((QDl + KDl) / 16) * str_D, KDl, D, str_D);
+        lw.wo = reg(lp.wo, D, QDl, str_QD);
         lw.rms_ffn_weight = (float*)lp.rms_ffn;
-        lw.w_gate = reg(lp.gateup, F, D, 2 * str_D);
-        lw.w_up = reg(lp.gateup + str_D, F, D, 2 * str_D);
-        lw.w_down = reg(lp.down, D, F, str_F);
+        lw.w_gate = reg(lp.gateup, Fl, D, 2 * str_D);
+        lw.w_up = reg(lp.gateup + str_D, Fl, D, 2 * str_D);
+        lw.w_down = reg(lp.down, D, Fl, str_F);
     }
     {
         WeightEntry e{nullptr, (int)V, (int)D, (int)Kb_D, 0, m->embed};
@@ -287,8 +315,14 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     const int T = num_tokens, B = num_outputs;
     if (T <= 0) return;
     if (T > p->max_seq_len || B > p->max_seq_len) NVLLM_FATAL("batch of %d tokens exceeds the workspace (%d)", T, p->max_seq_len);
-    const int D = p->dim, F = p->hidden_dim, hd = p->head_dim, H = p->n_heads, KVH = p->n_kv_heads;
+    // H, KVH, F, QD, KD: what THIS process computes (its tensor-parallel slice; the whole model when world == 1)
+    const int D = p->dim, F = m->sh.hidden, hd = p->head_dim, H = m->sh.n_heads, KVH = m->sh.n_kv_heads;
     const int QD = H * hd, KD = KVH * hd, V = p->vocab_size;
+    const bool partial = tp().active;   // wo / w_down leave partial sums that are all-reduced
+    if (partial && (m->sh.world != tp().world || m->sh.rank != tp().rank))
+        NVLLM_FATAL("these weights were loaded as rank %d of %d, the process is now rank %d of %d", m->sh.rank,
+                    m->sh.world, tp().rank, tp().world);
+    if (!partial && m->sh.world != 1) NVLLM_FATAL("weights of a %d-way split need nvllm_tp_init before the forward pass", m->sh.world);
     const float eps = 1e-5f;  // model.c:361,388,396
 
     StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
@@ -338,9 +372,17 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         // x += att . wo^T; a16_x = x * rms_ffn; ss_b                              (model.c:385-388)
         WeightEntry wwo{lp.wo, D, QD, QD / 32, (long)(QD / 32) * TILE_HALVES, nullptr};
         GemmEpilogue e2;
-        e2.kind = GemmEpilogue::RESID_A16;
-        e2.x = s->x; e2.gain_next = lp.rms_ffn; e2.a16_out = a16_x; e2.ss_out = ss_b;
-        launch_gemm(wwo, lp.wo, D, a16_att, T, e2, 0, PC_GEMM_WO);
+        if (!partial) {
+            e2.kind = GemmEpilogue::RESID_A16;
+            e2.x = s->x; e2.gain_next = lp.rms_ffn; e2.a16_out = a16_x; e2.ss_out = ss_b;
+            launch_gemm(wwo, lp.wo, D, a16_att, T, e2, 0, PC_GEMM_WO);
+        } else {   // this rank's heads only: sum over the ranks, then the same tail as a separate launch
+            e2.kind = GemmEpilogue::F32;
+            e2.out = s->xb; e2.ldo = D;
+            launch_gemm(wwo, lp.wo, D, a16_att, T, e2, 0, PC_GEMM_WO);
+            tp_allreduce(s->xb, (size_t)T * D);
+            launch_resid_prescale(s->x, s->xb, a16_x, ss_b, lp.rms_ffn, T, D);
+        }
         // hb = silu(rmsnorm(x).w_gate^T) * (rmsnorm(x).w_up^T)                    (model.c:388-391)
         WeightEntry wgu{lp.gateup, 2 * F, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
         GemmEpilogue e3;
@@ -351,11 +393,20 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         // x += hb . w_down^T; a16_x = x * (next norm's gain); ss_a                (model.c:392-393,361|396)
         WeightEntry wdn{lp.down, D, F, F / 32, (long)(F / 32) * TILE_HALVES, nullptr};
         GemmEpilogue e4;
-        e4.kind = GemmEpilogue::RESID_A16;
-        e4.x = s->x;
-        e4.gain_next = l + 1 < p->n_layers ? m->layers[l + 1].rms_att : m->rms_final;
-        e4.a16_out = a16_x; e4.ss_out = ss_a;
-        launch_gemm(wdn, lp.down, D, a16_h, T, e4, 0, PC_GEMM_DOWN);
+        const float* gain_next = l + 1 < p->n_layers ? m->layers[l + 1].rms_att : m->rms_final;
+        if (!partial) {
+            e4.kind = GemmEpilogue::RESID_A16;
+            e4.x = s->x;
+            e4.gain_next = gain_next;
+            e4.a16_out = a16_x; e4.ss_out = ss_a;
+            launch_gemm(wdn, lp.down, D, a16_h, T, e4, 0, PC_GEMM_DOWN);
+        } else {   // this rank's hidden columns only
+            e4.kind = GemmEpilogue::F32;
+            e4.out = s->xb; e4.ldo = D;
+            launch_gemm(wdn, lp.down, D, a16_h, T, e4, 0, PC_GEMM_DOWN);
+            tp_allreduce(s->xb, (size_t)T * D);
+            launch_resid_prescale(s->x, s->xb, a16_x, ss_a, gain_next, T, D);
+        }
     }
     // logits only for the rows named by output_indices                            (model.c:396,411-418)
     bool identity = B == T;

@@ -85,6 +85,17 @@ struct Runtime {
 Runtime& rt();
 void ensure_init();
 
+// Tensor parallelism (tp.hip).  `active` selects the forward pass that leaves the two
+// residual projections as partial sums and all-reduces them.
+struct TpState {
+    int rank = 0, world = 1;
+    bool active = false;
+    nvllm_allreduce_fn fn = nullptr;   // caller-supplied exchange; null = RCCL
+    void* ctx = nullptr;
+};
+TpState& tp();
+void tp_allreduce(float* buf, size_t count);   // in place, on the library stream
+
 // Grow-only device scratch, one buffer per slot.
 enum WsSlot {
     WS_A16_X = 0,   // normalised activations feeding qkv / gate-up / classifier
@@ -244,6 +255,9 @@ int attn_tokens_per_item(int H, int KVH);
 // x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 32j..32j+31
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
                            const float* gain, int T, int D);
+// x[t,:] += y[t,:]; a16 = x * gain in hi/lo tiles; ss as above (the tail of a residual projection
+// whose sums were completed outside the projection kernel)
+void launch_resid_prescale(float* x, const float* y, __half* a16, float* ss, const float* gain, int T, int D);
 // rows idx[r] of an a16 activation (and of its ss table) compacted to rows r = 0..B-1
 void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const float* src_ss, const int* idx,
                        int B, int K, int ss_tiles);

@@ -211,6 +211,12 @@ void accum(float* a, float* b, int size) {
 void init_kv_cache_manager(KVCacheManager* mgr, int block_size, int num_blocks, int n_layers,
                            int n_kv_heads, int head_dim) {
     ensure_init();
+    // tensor parallelism: the caller passes the model's head count (it sizes the pool from Config);
+    // this process stores and reads the K/V of its own heads only
+    if (tp().active && tp().world > 1) {
+        if (n_kv_heads % tp().world) NVLLM_FATAL("%d kv heads do not divide over %d tensor-parallel ranks", n_kv_heads, tp().world);
+        n_kv_heads /= tp().world;
+    }
     mgr->block_size = block_size;
     mgr->num_blocks = num_blocks;
     mgr->free_blocks_count = num_blocks;

@@ -69,6 +69,7 @@ def _declared_functions():
     for h in ("backend.h", "ops.h", "model.h", "sampler.h", "nvllm.h"):
         text = open(os.path.join(INC, h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^typedef[^;{]*\(\s*\*[^;]*;", "", text, flags=re.M)   # function-pointer types are not entry points
         for m in re.finditer(r"^[A-Za-z_][A-Za-z0-9_ \*]*?\b([a-z_][a-z0-9_]*)\s*\(", text, flags=re.M):
             names.add(m.group(1))
     # ASCII dashboards: declared for the driver's benefit, provided by its own visualizer.c

@@ -1,0 +1,108 @@
+"""Tensor parallelism of the forward pass: the per-rank slices (heads, hidden columns),
+the partial-sum projections and the all-reduce hook, against the CPU oracle run on the
+whole model."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from nvllm_amd import capi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT_TOL = 2e-4     # as for the single-process forward pass
+LOGITS_TOL = 2e-2
+
+GQA = dict(dim=256, hidden_dim=512, n_layers=3, n_heads=8, n_kv_heads=4, vocab_size=600, max_seq_len=160)
+
+
+def _run_and_compare(hip, oracle, path, shape, tol):
+    prompts = synth.make_requests(4, 3, 40, shape.vocab_size, seed=17)
+    kw = dict(n_new=20, arrivals=[0, 1, 1, 4], collect_logits=True, chunk_size=16, temperature=0.0, max_steps=400)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    g = util.run_engine(hip, path, prompts, **kw)
+    np.testing.assert_array_equal(g["trace"], o["trace"])
+    for a, b in zip(g["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+    worst = max(float(np.abs(a["logits"] - b["logits"]).max()) for a, b in zip(g["steps"], o["steps"]))
+    assert worst < tol, worst
+    return o
+
+
+def test_partial_sum_path_with_a_single_rank(hip, oracle, tmp_models):
+    """world = 1 with a caller-supplied exchange: the projections that return to the
+    residual width leave plain sums, the exchange (here: nothing to add) runs between
+    them and the residual kernel, once after wo and once after w_down per layer."""
+    path, shape = tmp_models("tiny", seed=3, **GQA)
+    calls = []
+
+    def allreduce(ctx, buf, count, stream):
+        calls.append(count)
+
+    cb = capi.ALLREDUCE_FN(allreduce)
+    assert hip.nvllm_tp_init_custom(0, 1, cb, None) == 0
+    try:
+        o = _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)
+    finally:
+        hip.nvllm_tp_finalize()
+    assert len(calls) == 2 * shape.n_layers * len(o["steps"])
+    assert sum(calls) == 2 * shape.n_layers * shape.dim * sum(len(s["tokens"]) for s in o["steps"])
+    # and the fused single-process path is back afterwards
+    _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)
+
+
+def test_rccl_communicator_of_one_rank(hip, oracle, tmp_models):
+    """The RCCL plumbing end to end on the one GPU of the box: unique id, communicator,
+    ncclAllReduce on the library stream between the projection and the residual kernel."""
+    path, shape = tmp_models("tiny", seed=3, **GQA)
+    ident = (C.c_char * capi.TP_ID_BYTES)()
+    assert hip.nvllm_tp_unique_id(ident) == 0
+    assert hip.nvllm_tp_init(0, 1, ident) == 0
+    try:
+        _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)
+    finally:
+        hip.nvllm_tp_finalize()
+
+
+def test_setup_is_refused_twice_and_for_bad_placements(hip):
+    cb = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
+    assert hip.nvllm_tp_init_custom(2, 2, cb, None) == -1
+    assert hip.nvllm_tp_init_custom(0, 1, cb, None) == 0
+    try:
+        assert hip.nvllm_tp_init_custom(0, 1, cb, None) == -1
+    finally:
+        hip.nvllm_tp_finalize()
+    assert (hip.nvllm_tp_rank(), hip.nvllm_tp_world()) == (0, 1)
+
+
+@pytest.mark.parametrize("world,kv_bytes,over", [
+    (2, 4, dict(hidden_dim=192)),          # "tiny": 4 heads / 2 kv heads of width 16
+    (2, 2, GQA),
+    (4, 4, GQA),                           # one kv head (two query heads) per rank
+])
+def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_bytes, over):
+    """`world` processes, each with its slice of the weights and of the KV pool, the
+    exchange staged through the host (gloo); every rank must reproduce the oracle's
+    tokens, allocation trace and logits."""
+    path, shape = tmp_models("tiny", seed=5, **over)
+    spec = dict(name="tiny", over=over, model_path=path, n_seqs=5, seed=23, n_new=16, chunk=12, kv_bytes=kv_bytes,
+                out_dir=str(tmp_path))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    port = 29620 + world + kv_bytes
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "tp_worker.py"), json.dumps(spec)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    for rank in range(world):
+        r = json.load(open(tmp_path / f"rank{rank}.json"))
+        assert r["same_trace"] and r["same_tokens"], r
+        assert r["worst"] < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), r
+        assert r["allreduce_calls"] == 2 * r["n_layers"] * r["steps"]
+        assert r["allreduce_floats"] == 2 * r["n_layers"] * r["dim"] * r["tokens_forwarded"]

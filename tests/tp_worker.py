@@ -1,0 +1,73 @@
+"""One tensor-parallel rank for tests/test_gpu_tp.py (started by torch.distributed.run).
+
+Every rank loads its slice of the same model file into the HIP library, with the
+all-reduce supplied by this script: the partial sums go through the host and a gloo
+all_reduce, so that several ranks can share the one GPU of a test box (RCCL itself
+refuses two ranks on one device).  Every rank also runs the CPU oracle on the whole
+model and compares."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from nvllm_amd import capi, synth  # noqa: E402
+from tests import util  # noqa: E402
+
+
+def main():
+    spec = json.loads(sys.argv[1])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shape = synth.ModelShape.named(spec["name"], **spec["over"])
+    path = spec["model_path"]
+    prompts = synth.make_requests(spec["n_seqs"], 3, 40, shape.vocab_size, seed=spec["seed"])
+    kw = dict(n_new=spec["n_new"], arrivals=[(2 * i) % 3 for i in range(spec["n_seqs"])], collect_logits=True,
+              chunk_size=spec["chunk"], temperature=0.0, max_steps=600)
+
+    oracle = capi.load_oracle()
+    want = util.run_engine(oracle, path, prompts, **kw)
+
+    hip = capi.load_hip()
+    hip.init_ops()
+    hip.nvllm_set_kv_elem_bytes(spec["kv_bytes"])
+    calls = {"n": 0, "floats": 0}
+
+    def allreduce(ctx, buf, count, stream):
+        hip.device_sync()                                     # the partial sums are complete
+        host = np.empty(count, np.float32)
+        hip.device_memcpy(host.ctypes.data, buf, host.nbytes, capi.DEVICE_TO_HOST)
+        t = torch.from_numpy(host)
+        dist.all_reduce(t)                                    # sum over the ranks
+        hip.device_memcpy(buf, host.ctypes.data, host.nbytes, capi.HOST_TO_DEVICE)
+        calls["n"] += 1
+        calls["floats"] += count
+
+    cb = capi.ALLREDUCE_FN(allreduce)
+    assert hip.nvllm_tp_init_custom(rank, world, cb, None) == 0
+    assert (hip.nvllm_tp_rank(), hip.nvllm_tp_world()) == (rank, world)
+    got = util.run_engine(hip, path, prompts, **kw)
+    hip.nvllm_tp_finalize()
+
+    same_tokens = all(np.array_equal(a, b) for a, b in zip(got["histories"], want["histories"]))
+    same_trace = np.array_equal(got["trace"], want["trace"])
+    worst = max(float(np.abs(a["logits"] - b["logits"]).max()) for a, b in zip(got["steps"], want["steps"]))
+    tokens_forwarded = int(sum(len(s["tokens"]) for s in want["steps"]))
+    out = dict(rank=rank, world=world, same_tokens=bool(same_tokens), same_trace=bool(same_trace), worst=worst,
+               allreduce_calls=calls["n"], allreduce_floats=calls["floats"], steps=len(want["steps"]),
+               tokens_forwarded=tokens_forwarded, n_layers=shape.n_layers, dim=shape.dim)
+    with open(os.path.join(spec["out_dir"], f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
