@@ -12,6 +12,11 @@ block pool; there is no data-path collective, so scaling is "weak".
     python bench.py --gpus 1 --steps 64 --warmup 8
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+With --tp the N processes hold ONE model instead (BASELINE.json configs[4]: Llama-2-7B
+shape, batch 128): heads and MLP columns are split over the ranks and the two partial
+sums per layer are all-reduced with RCCL on the library's stream; every rank runs the
+same 128 requests, `value` counts them once and scaling is "strong".
+
 Rank 0 prints ONE JSON line.  `value` is decode tokens/s over all ranks with the
 batch already resident in HBM (the only host traffic inside a step is the 64-entry
 integer batch description going up and 64 token ids coming back).
@@ -43,11 +48,13 @@ def shard_requests(n_requests_per_gpu: int, rank: int, world: int):
     return [r for r in range(total) if r % world == rank]
 
 
-def algorithmic_bytes_per_decode_step(shape, batch, ctx_lens, kv_bytes):
-    """Bytes one decode step must move at least once: every weight once, K/V of
-    every cached position once per kv head, the new K/V rows, the token ids."""
-    D, F, L, V = shape.dim, shape.hidden_dim, shape.n_layers, shape.vocab_size
-    QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
+def algorithmic_bytes_per_decode_step(shape, batch, ctx_lens, kv_bytes, tp_world=1):
+    """Bytes one decode step must move at least once ON ONE GPU: every weight once, K/V
+    of every cached position once per kv head, the new K/V rows, the token ids.  Under
+    tensor parallelism a GPU holds 1/world of the heads and MLP columns and all of the
+    classifier."""
+    D, F, L, V = shape.dim, shape.hidden_dim // tp_world, shape.n_layers, shape.vocab_size
+    QD, KD = shape.n_heads * shape.head_dim // tp_world, shape.n_kv_heads * shape.head_dim // tp_world
     weights = 2 * (L * (2 * D * QD + 2 * D * KD + 3 * D * F) + V * D) + 4 * (2 * L + 1) * D
     kv_row = L * 2 * KD * kv_bytes
     kv_read = sum(c + 1 for c in ctx_lens) * kv_row
@@ -91,6 +98,16 @@ class DistEnv:
         self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return float(t.item())
 
+    def broadcast_bytes(self, payload: bytes | None, n: int) -> bytes:
+        """`n` bytes from rank 0 to every rank."""
+        if not self.dist:
+            return payload
+        t = self.torch.zeros(n, dtype=self.torch.uint8, device=self.device)
+        if self.rank == 0:
+            t.copy_(self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
@@ -118,7 +135,9 @@ def ensure_model(path, shape, seed, env):
     want = 28 + 2 * shape.n_params(shared=False)
     if env.rank == 0 and not (os.path.exists(path) and os.path.getsize(path) == want):
         t0 = time.time()
-        synth.write_model(path, shape, seed=seed)
+        big = want > 4e9
+        synth.write_model(path, shape, seed=seed,
+                          progress=(lambda name: print(f"bench: wrote {name} ({time.time() - t0:.0f}s)", file=sys.stderr, flush=True)) if big else None)
         print(f"bench: wrote {path} ({want / 1e9:.2f} GB) in {time.time() - t0:.1f}s", file=sys.stderr)
     env.barrier()
 
@@ -129,6 +148,18 @@ def run_gpu(args, env, shape, model_path):
     lib.nvllm_set_device(env.local_rank)
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
     lib.nvllm_set_logits_mode(1)    # only token ids return to the host
+    if args.tp:
+        # one RCCL communicator over all ranks, owned by the library: its all-reduces run on the
+        # library's stream.  (With one rank the same code path runs, the sums have one term.)
+        ident = None
+        if env.rank == 0:
+            buf = (C.c_char * capi.TP_ID_BYTES)()
+            if lib.nvllm_tp_unique_id(buf) != 0:
+                raise SystemExit("bench: RCCL is not available")
+            ident = bytes(buf.raw)
+        ident = env.broadcast_bytes(ident, capi.TP_ID_BYTES)
+        if lib.nvllm_tp_init(env.rank, env.world, ident) != 0:
+            raise SystemExit("bench: tensor-parallel setup failed")
     B = args.batch
     # sequences that finish their prefill early already decode while the others are
     # still prefilling (continuous batching), so budget those steps too
@@ -138,8 +169,12 @@ def run_gpu(args, env, shape, model_path):
     n_new = prefill_steps + args.warmup + args.steps + args.profile_steps + 8
     if args.prompt_len + n_new > args.max_seq_len:
         raise SystemExit(f"prompt {args.prompt_len} + {n_new} new tokens exceeds max_seq_len {args.max_seq_len}")
-    ids = shard_requests(B, env.rank, env.world)
-    prompts = synth.make_requests(B * env.world, args.prompt_len, args.prompt_len, shape.vocab_size, seed=11)
+    if args.tp:      # every rank runs the same requests
+        ids = list(range(B))
+        prompts = synth.make_requests(B, args.prompt_len, args.prompt_len, shape.vocab_size, seed=11)
+    else:
+        ids = shard_requests(B, env.rank, env.world)
+        prompts = synth.make_requests(B * env.world, args.prompt_len, args.prompt_len, shape.vocab_size, seed=11)
     eng = capi.Engine(lib, model_path, B, chunk_size=args.chunk, temperature=0.0,
                       max_seq_len=args.max_seq_len, max_steps=1 << 30)
     for slot, r in enumerate(ids):
@@ -165,7 +200,7 @@ def run_gpu(args, env, shape, model_path):
     st = eng.stats()
     assert st.decode_step_tokens == (args.warmup + args.steps) * B, "a timed step was not a pure decode step"
     ctx_mid = [c + args.warmup + args.steps // 2 for c in ctx0]
-    step_bytes = algorithmic_bytes_per_decode_step(shape, B, ctx_mid, args.kv_bytes)
+    step_bytes = algorithmic_bytes_per_decode_step(shape, B, ctx_mid, args.kv_bytes, env.world if args.tp else 1)
 
     # ---- per-kernel durations from HIP events on the library stream (same workload,
     #      the steps right after the timed region; events would perturb the timing)
@@ -184,6 +219,8 @@ def run_gpu(args, env, shape, model_path):
                                                              bytes=by.value, flops=fl.value)
     hist = eng.history(0)[-4:].tolist()
     eng.close()
+    if args.tp:
+        lib.nvllm_tp_finalize()
     return dict(elapsed=elapsed, prefill_s=prefill_s, prefill_tokens=prefill_tokens, step_bytes=step_bytes,
                 prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist)
 
@@ -230,17 +267,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--model", default="tinyllama-1.1b")
-    ap.add_argument("--batch", type=int, default=64, help="concurrent sequences per GPU")
-    ap.add_argument("--prompt-len", type=int, default=1024)
+    ap.add_argument("--tp", action="store_true",
+                    help="the ranks hold ONE model, split by heads / MLP columns, with RCCL all-reduces (default workload: "
+                         "llama2-7b shape, batch 128, 128-token prompts)")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--batch", type=int, default=None, help="concurrent sequences per GPU (per model under --tp)")
+    ap.add_argument("--prompt-len", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=512)
-    ap.add_argument("--max-seq-len", type=int, default=2048)
+    ap.add_argument("--max-seq-len", type=int, default=None)
     ap.add_argument("--kv-bytes", type=int, default=2, choices=(2, 4),
                     help="KV pool element size: 2 = fp16 pages (default; parity covered by the fp16-pool GPU tests), 4 = the reference's fp32 rows")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
     args = ap.parse_args()
+    defaults = (("llama2-7b", 128, 128, 512) if args.tp else ("tinyllama-1.1b", 64, 1024, 2048))
+    for name, val in zip(("model", "batch", "prompt_len", "max_seq_len"), defaults):
+        if getattr(args, name) is None:
+            setattr(args, name, val)
 
     from nvllm_amd import synth
     env = DistEnv(args.gpus)
@@ -251,8 +295,8 @@ def main():
     r = run_gpu(args, env, shape, model_path)
     N, K, B = env.world, args.steps, args.batch
     ms_per_step = r["elapsed"] / K * 1e3
-    value = B * N * K / r["elapsed"]
-    prefill_tps = env.reduce(r["prefill_tokens"] / r["prefill_s"], "SUM")
+    value = B * (1 if args.tp else N) * K / r["elapsed"]
+    prefill_tps = env.reduce(r["prefill_tokens"] / r["prefill_s"], "MAX" if args.tp else "SUM")
 
     if env.rank == 0:
         roofline, by_kernel = None, {}
@@ -267,7 +311,7 @@ def main():
                     g[k] += d[k]
             pmc = {}
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
-            if os.path.exists(pmc_path) and args.model == "tinyllama-1.1b" and args.batch == 64 and args.kv_bytes == 2:
+            if os.path.exists(pmc_path) and args.model == "tinyllama-1.1b" and args.batch == 64 and args.kv_bytes == 2 and not args.tp:
                 pmc = json.load(open(pmc_path))["kernels"]     # measured on this workload in separate --pmc passes
             def roof(name):
                 d = by_kernel[name]
@@ -283,20 +327,21 @@ def main():
             roofline = roof(max(by_kernel, key=lambda k: by_kernel[k]["total_ms"]))   # the kernel the step spends most time in
             by_kernel = {k: roof(k) for k in by_kernel}
         cpu = None
-        if N == 1 and args.cpu_steps > 0:
+        if N == 1 and args.cpu_steps > 0 and not args.tp:
             cpu = cpu_baseline(args, shape, model_path)
         step_gbs = r["step_bytes"] / (ms_per_step * 1e-3) / 1e9
         line = {
-            "metric": "decode tokens/sec (node) + % HBM peak, TinyLlama-1.1B paged batch 64",
+            "metric": (f"decode tokens/sec (node) + % HBM peak, Llama-2-7B-shape TP={N} batch {B}" if args.tp else
+                       "decode tokens/sec (node) + % HBM peak, TinyLlama-1.1B paged batch 64"),
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if args.tp else "weak",
             "vs_baseline": None, "dtype": "f32 (fp16 weights as hi/lo-split fp16 MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.model} shape, random-init fp16 model.bin, {B} concurrent requests per GPU, "
                                    f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
                                    f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
                                    f"mean context {r['ctx']} in the timed region",
-                       "batch_per_gpu": B, "parallelism": f"dp{N}" if N > 1 else "single", "kv_elem_bytes": args.kv_bytes},
+                       "batch_per_gpu": B, "parallelism": f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
             "cpu_baseline": cpu,

@@ -87,13 +87,15 @@ def _write_norm(f, n: int, rng: np.random.Generator, dtype) -> None:
 
 
 def write_model(path: str, shape: ModelShape, seed: int = 0, dtype: str = "f16",
-                shared: bool = False, rope_tail: bool = False) -> int:
+                shared: bool = False, rope_tail: bool = False, progress=None) -> int:
     """Write a random-init model file; returns its size in bytes.
 
     Matrices: k/4096 with |k| <= 82 (about +-0.02); embedding (and a separate
     classifier): k/128 with |k| <= 64 (about +-0.5); norm gains 1 + k/64.
     ``rope_tail`` appends the legacy llama2.c RoPE tables (fp32 shared files only).
+    ``progress(name)`` is called after every tensor kind (large files take a while).
     """
+    progress = progress or (lambda name: None)
     np_dtype = {"f16": np.float16, "f32": np.float32}[dtype]
     D, F, L, V = shape.dim, shape.hidden_dim, shape.n_layers, shape.vocab_size
     QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
@@ -104,14 +106,16 @@ def write_model(path: str, shape: ModelShape, seed: int = 0, dtype: str = "f16",
         _write_random(f, V * D, rng, 64, 128.0, np_dtype)              # token_embedding_table
         for _ in range(L):
             _write_norm(f, D, rng, np_dtype)                           # rms_att_weight
-        for n in (D * QD, D * KD, D * KD, QD * D):                      # wq, wk, wv, wo
+        for name, n in (("wq", D * QD), ("wk", D * KD), ("wv", D * KD), ("wo", QD * D)):
             for _ in range(L):
                 _write_random(f, n, rng, 82, 4096.0, np_dtype)
+            progress(name)
         for _ in range(L):
             _write_norm(f, D, rng, np_dtype)                           # rms_ffn_weight
-        for n in (D * F, F * D, D * F):                                 # w_gate, w_down, w_up
+        for name, n in (("w_gate", D * F), ("w_down", F * D), ("w_up", D * F)):
             for _ in range(L):
                 _write_random(f, n, rng, 82, 4096.0, np_dtype)
+            progress(name)
         _write_norm(f, D, rng, np_dtype)                               # rms_final_weight
         if not shared:
             _write_random(f, V * D, rng, 64, 2048.0, np_dtype)         # lm_head
