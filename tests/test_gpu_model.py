@@ -218,3 +218,21 @@ def test_matmul_accepts_load_model_handles(hip, oracle, tmp_models):
         got = res["hip"][key]
         # fp16 weights are exact in both; the activation enters as hi+lo fp16 (~2^-22 relative)
         np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * np.abs(want).max() + 1e-7, err_msg=str(key))
+
+
+def test_stories42m_shape_with_32_concurrent_requests(hip, oracle, tmp_models):
+    """BASELINE.json configs[1]'s shape and concurrency (TinyStories-42M, 32 requests, continuous
+    batching with staggered arrivals and block recycling), shortened so that the oracle stays cheap."""
+    path, shape = tmp_models("stories42M", max_seq_len=256)
+    prompts = synth.make_requests(32, 8, 48, shape.vocab_size, seed=19)
+    kw = dict(n_new=[6 + (i % 5) * 4 for i in range(32)], arrivals=[(7 * i) % 6 for i in range(32)], collect_logits=True,
+              chunk_size=64, temperature=0.0, max_steps=400, recycle_blocks=1)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare_runs(g, o)
+    assert worst < LOGITS_TOL / 10, worst
