@@ -38,77 +38,9 @@
 // the projection).
 #include <vector>
 
-#include "nvllm_internal.h"
+#include "gemm_common.h"
 
 namespace nvllm {
-
-typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-typedef float f4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-
-struct GemmArgs {
-    const __half* W;
-    long nb_stride;   // halves between 16-row blocks
-    int NB;           // 16-row blocks
-    int Kb;           // k tiles
-    const __half* A;  // activation tiles [Tb][Kb][2][512]
-    int Tb;
-    int N, T;
-    int kb_per_split;
-    int ksplit;
-    float* slab;      // [tile][slice][round][item] float4
-    unsigned* counters;
-    GemmEpilogue e;
-};
-
-__device__ __forceinline__ float silu_mul(float g, float u) {
-    // reference layers.c:156-158: g / (1 + expf(-g)) * u
-    return __fmul_rn(__fdiv_rn(g, __fadd_rn(1.0f, expf(-g))), u);
-}
-
-__device__ __forceinline__ void split16_4(const float* y, __half* hi, __half* lo) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float c = fminf(fmaxf(y[r], -65504.f), 65504.f);
-        hi[r] = __float2half_rn(c);
-        lo[r] = __float2half_rn(c - __half2float(hi[r]));
-    }
-}
-
-// store 4 consecutive k of token t into hi/lo tiles (n % 4 == 0)
-__device__ __forceinline__ void store_a16_4(__half* a16, int Kb_out, int t, int n, const float* y) {
-    alignas(8) __half hi[4], lo[4];
-    split16_4(y, hi, lo);
-    const size_t tile = ((size_t)(t >> 4) * Kb_out + (n >> 5)) * 2;
-    const size_t off = (size_t)((t & 15) + 16 * ((n >> 3) & 3)) * 8 + (n & 7);
-    *reinterpret_cast<uint2*>(a16 + tile * TILE_HALVES + off) = *reinterpret_cast<uint2*>(hi);
-    *reinterpret_cast<uint2*>(a16 + (tile + 1) * TILE_HALVES + off) = *reinterpret_cast<uint2*>(lo);
-}
-
-template <typename KVT>
-__device__ __forceinline__ void kv_put4(KVT* dst, const float* y);
-template <>
-__device__ __forceinline__ void kv_put4<float>(float* dst, const float* y) {
-    *reinterpret_cast<float4*>(dst) = make_float4(y[0], y[1], y[2], y[3]);
-}
-__device__ __forceinline__ __half kv_sat_half(float v) {   // finite fp16 only: masked keys need 0 * finite = 0
-    return __float2half_rn(fminf(fmaxf(v, -65504.f), 65504.f));
-}
-template <>
-__device__ __forceinline__ void kv_put4<__half>(__half* dst, const float* y) {
-    alignas(8) __half h[4] = {kv_sat_half(y[0]), kv_sat_half(y[1]), kv_sat_half(y[2]), kv_sat_half(y[3])};
-    *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(h);
-}
-// four consecutive dims of one key in a V page: 4 halves apart
-template <typename KVT>
-__device__ __forceinline__ void kv_put4_strided(KVT* dst, const float* y);
-template <>
-__device__ __forceinline__ void kv_put4_strided<float>(float*, const float*) {}
-template <>
-__device__ __forceinline__ void kv_put4_strided<__half>(__half* dst, const float* y) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) dst[4 * e] = kv_sat_half(y[e]);
-}
 
 template <int NBW, int TB, int NW, int EPI, typename KVT>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
@@ -508,6 +440,25 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     a.N = N;
     a.T = T;
     a.e = epi;
+    if (epi.kind == GemmEpilogue::SWIGLU_A16) {
+        if ((N / 2) % 32 != 0 || a.NB % 2 != 0) NVLLM_FATAL("fused gate/up projection needs hidden_dim %% 32 == 0, got %d", N / 2);
+        a.e.Kb_out = cdiv(N / 2, 32);
+    } else if (epi.kind == GemmEpilogue::RESID_A16) {
+        if (N % 32 != 0) NVLLM_FATAL("fused residual epilogue needs a width that is a multiple of 32, got %d", N);
+        a.e.Kb_out = cdiv(N, 32);
+    }
+    const double out_bytes = epi.kind == GemmEpilogue::SWIGLU_A16 ? (double)T * N * 2.0
+                             : epi.kind == GemmEpilogue::RESID_A16 ? (double)T * N * 12.0
+                                                                   : (double)T * N * 4.0;
+    const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 + out_bytes;
+    // Hundreds of tokens (prefill chunks): the contraction is dense enough for the
+    // LDS-shared 128 x 128 tiles of gemm_prefill.hip.
+    static const int pf_min_t = getenv("NVLLM_GEMM_PREFILL_T") ? atoi(getenv("NVLLM_GEMM_PREFILL_T")) : 256;
+    if (force_ksplit <= 0 && T >= pf_min_t) {
+        ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
+        launch_gemm_prefill(a);
+        return 1;
+    }
     int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
     int nbw = GEMM_NBW;
     int ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, w.K, T);
@@ -562,18 +513,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         const size_t tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
         a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles_n * tiles_t * ks * tile_bytes);
     }
-    if (epi.kind == GemmEpilogue::SWIGLU_A16) {
-        if ((N / 2) % 32 != 0 || a.NB % 2 != 0) NVLLM_FATAL("fused gate/up projection needs hidden_dim %% 32 == 0, got %d", N / 2);
-        a.e.Kb_out = cdiv(N / 2, 32);
-    } else if (epi.kind == GemmEpilogue::RESID_A16) {
-        if (N % 32 != 0) NVLLM_FATAL("fused residual epilogue needs a width that is a multiple of 32, got %d", N);
-        a.e.Kb_out = cdiv(N, 32);
-    }
     const dim3 grid(tiles_n, ks, tiles_t);
-    const double out_bytes = epi.kind == GemmEpilogue::SWIGLU_A16 ? (double)T * N * 2.0
-                             : epi.kind == GemmEpilogue::RESID_A16 ? (double)T * N * 12.0
-                                                                   : (double)T * N * 4.0;
-    const double bytes = (double)N * w.K * 2.0 + (double)T * w.K * 4.0 + out_bytes;
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
     if (nbw == 6) {

@@ -236,3 +236,26 @@ def test_stories42m_shape_with_32_concurrent_requests(hip, oracle, tmp_models):
         hip.nvllm_set_kv_elem_bytes(before)
     worst = _compare_runs(g, o)
     assert worst < LOGITS_TOL / 10, worst
+
+
+@pytest.mark.parametrize("kv_bytes,shape_kw", [
+    (2, dict(dim=256, hidden_dim=512, n_layers=3, n_heads=8, n_kv_heads=4, vocab_size=600, max_seq_len=1024)),
+    (4, dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=1000, max_seq_len=768)),   # head_dim 48; widths that are not multiples of 128
+])
+def test_prefill_batches_of_hundreds_of_tokens(hip, oracle, tmp_models, kv_bytes, shape_kw):
+    """Forward passes that carry several hundred tokens (whole prompts / large chunks of several
+    sequences at once) take the projections' dense-contraction kernel: all four epilogues, ragged
+    token and feature edges, decode rows mixed in."""
+    path, shape = tmp_models("tiny", seed=61, **shape_kw)
+    prompts = synth.make_requests(6, 90, 300, shape.vocab_size, seed=62)
+    kw = dict(n_new=5, arrivals=[0, 0, 0, 1, 1, 3], collect_logits=True, chunk_size=256, temperature=0.0, max_steps=200)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    assert max(len(s["tokens"]) for s in o["steps"]) >= 512
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(kv_bytes)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare_runs(g, o)
+    assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), worst
