@@ -4,18 +4,32 @@
 // At 64 tokens (gemm.hip) every weight byte feeds 2*64 flops and the waves of a
 // workgroup split K, each pulling its own operands.  From a few hundred tokens on the
 // work is bound by the matrix cores and by the operand traffic INTO the CU, so here a
-// workgroup owns a 128-feature x 128-token output tile and its four waves (2 x 2, each
+// workgroup owns an output tile of 128 features x 128 tokens and its waves (2 x 2, each
 // 64 x 64 = 4 x 4 accumulator tiles) walk K together: per K-step the workgroup's 8 weight
 // tiles and 8 x 2 activation tiles (hi, lo planes) are copied global -> LDS once, by
 // direct-to-LDS loads, and every wave reads the 4 + 8 tiles it needs from LDS.  That is
 // 24 KiB into the CU per 128 MFMAs instead of 48 KiB when each wave loads for itself.
+// Two forms:
+//   4 waves: for projections that make more workgroups than CUs; up to three share a CU
+//            and cover each other's waits;
+//   8 waves: for projections whose workgroups fit the chip at one per CU.  The second
+//            group of four waves takes the odd K-steps, so every SIMD has two waves to
+//            alternate between LDS reads and MFMAs and a barrier covers two K-steps; the
+//            two groups add their accumulators through LDS before the epilogue.
+// (256-feature tiles have the better operand traffic per MFMA and measured slower at
+// prefill sizes: too few workgroups, and the last round of them runs nearly empty.)
 //
 // Both operands are stored in matrix-core operand order, one 1-KiB tile per (16 rows,
 // 32 k), so a tile is copied by ONE wave instruction (64 lanes x 16 B, lane-linear in
 // LDS) and read back by one conflict-free ds_read_b128 per lane: no swizzle, no
-// transposition.  Two LDS buffers: the copy of step k+1 runs while step k is
-// multiplied; two workgroups fit a CU, so one computes while the other waits at its
-// barrier.
+// transposition.  The copies run ahead of the multiplication in a ring of LDS buffers
+// (24 KiB per K-step): each wave waits for its own copies of the step it is about to
+// read with a COUNTED s_waitcnt (later steps stay in flight), a raw s_barrier publishes
+// the step to the other waves and at the same time retires the buffer read one step
+// earlier, which is then refilled.  The ring depth follows the launch: a wide
+// projection makes several workgroups per CU, which cover each other's waits, so two
+// buffers (three workgroups fit a CU) are enough; a narrow one makes about one
+// workgroup per CU, which then keeps five steps in flight on its own.
 //
 // The epilogues are those of gemm.hip (F32, SWIGLU_A16, RESID_A16, ROPE_KV) applied
 // straight from the accumulators: a lane holds, per accumulator tile, four consecutive
@@ -27,113 +41,70 @@ namespace nvllm {
 
 namespace {
 
-constexpr int PF_FB = 8;   // 16-row weight blocks per workgroup tile (128 features)
-constexpr int PF_TB = 8;   // 16-token blocks per workgroup tile (128 tokens)
-constexpr int PF_STAGE_TILES = PF_FB + 2 * PF_TB;          // 24 tiles of 1 KiB per K-step
-constexpr int PF_STAGE_HALVES = PF_STAGE_TILES * TILE_HALVES;
-
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int EPI, typename KVT>
-__global__ __launch_bounds__(256, 2) void k_gemm_prefill(GemmArgs p, int tiles_n, int tiles_t) {
-    // one object holds all LDS: [2 buffers][24 tiles][512 halves], then 128 floats of 1/rms
-    __shared__ __attribute__((aligned(16))) __half lds[2 * PF_STAGE_HALVES + 2 * PF_TB * 16];
-    float* s_rinv = reinterpret_cast<float*>(lds + 2 * PF_STAGE_HALVES);
+// FW = 16-row weight blocks per wave (4 or 8), KG = groups of four waves that split the K-steps
+template <int FW, int KG>
+struct PfGeom {
+    static constexpr int FB = 2 * FW;                  // weight blocks per workgroup tile
+    static constexpr int TB = 8;                       // 16-token blocks per workgroup tile (128 tokens)
+    static constexpr int TPK = FB + 2 * TB;            // 1-KiB tiles per K-step: weights, then (hi, lo) per token block
+    static constexpr int STAGE_TILES = KG * TPK;       // a stage = KG consecutive K-steps = what one barrier publishes
+    static constexpr int STAGE_HALVES = STAGE_TILES * TILE_HALVES;
+    static constexpr int WAVES = 4 * KG;
+    static constexpr int CPW = STAGE_TILES / WAVES;    // copies per wave per stage (6 or 8)
+    static constexpr int RINV_HALVES = 2 * TB * 16;    // 128 floats in front of the ring
+};
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;   // this wave's 64 features x 64 tokens inside the tile
+// One wave copies one 1-KiB tile global -> LDS without passing through registers: lane l's
+// 16 bytes land at lds_byte_address + 16*l.  Written as an asm statement on purpose: the
+// compiler then keeps no account of the copy, and the waits below are the only ones (with
+// the builtin it drains every copy in flight before the next read of the LDS array).
+// M0 carries the LDS address and is restored inside the statement.
+__device__ __forceinline__ void copy_tile_to_lds(const __half* lane_src, unsigned lds_byte_address) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_src), "s"(lds_byte_address)
+                 : "memory");
+}
 
-    // Workgroups are dealt round-robin to the 8 XCDs.  Give every XCD a contiguous range
-    // of the (feature tile, token tile) sequence, token tiles fastest: the workgroups that
-    // run together behind one L2 then share a few weight tiles and all walk the same
-    // activations.
-    const int total = tiles_n * tiles_t;
-    int id = blockIdx.x;
-    {
-        const int xcd = id & 7, slot = id >> 3;
-        const int q = total >> 3, r = total & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int nb0 = (id / tiles_t) * PF_FB;
-    const int tb0 = (id % tiles_t) * PF_TB;
-
-    // ---- who copies what: tile q of a stage (0..7 weights, 8..23 activations) is copied
-    // by wave q / 6; per copy a lane-dependent source address and a wave-uniform LDS slot
-    const __half* src[6];
-    int step[6];
-#pragma unroll
-    for (int u = 0; u < 6; u++) {
-        const int q = wave * 6 + u;
-        if (q < PF_FB) {
-            src[u] = p.W + (size_t)min(nb0 + q, p.NB - 1) * p.nb_stride + lane * 8;
-            step[u] = TILE_HALVES;
-        } else {
-            const int tb = min(tb0 + ((q - PF_FB) >> 1), p.Tb - 1);
-            src[u] = p.A + ((size_t)tb * p.Kb * 2 + ((q - PF_FB) & 1)) * TILE_HALVES + lane * 8;
-            step[u] = 2 * TILE_HALVES;
+// wait until at most `stages` stages of this wave's copies (CPW each) are still in flight;
+// s_waitcnt takes an immediate
+template <int CPW>
+__device__ __forceinline__ void wait_copies_but(int stages) {
+    static_assert(CPW == 6 || CPW == 8, "immediates below");
+    if (CPW == 6) {
+        switch (stages) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        }
+    } else {
+        switch (stages) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
         }
     }
-    auto stage = [&](int kb, int buf) {
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(src[u] + (size_t)kb * step[u]),
-                                             (lds_void*)(lds + buf * PF_STAGE_HALVES + (wave * 6 + u) * TILE_HALVES), 16, 0, 0);
-    };
+}
 
-    f4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    // 1/rms of the tile's tokens from the producer's sums of squares (two threads per token)
-    if (p.e.ss_in != nullptr) {
-        const int tl = threadIdx.x & 127, part = threadIdx.x >> 7;
-        const int t = min(tb0 * 16 + tl, p.T - 1);
-        const int srow = p.e.ss_gather ? p.e.ss_gather[t] : t;
-        const float* sp = p.e.ss_in + (size_t)srow * p.e.ss_tiles;
-        float ss = 0.f;
-        for (int j = part; j < p.e.ss_tiles; j += 2) ss += sp[j];
-        // the two halves meet in the result array itself: the upper half writes, the lower adds
-        if (part == 1) s_rinv[tl] = ss;
-        __syncthreads();
-        if (part == 0) s_rinv[tl] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss + s_rinv[tl], (float)p.e.d_in), p.e.eps)));
-    }
-
-    const h8_t* lw = reinterpret_cast<const h8_t*>(lds) + (wr * 4) * 64 + lane;                 // weight tiles of this wave
-    const h8_t* la = reinterpret_cast<const h8_t*>(lds) + (PF_FB + wc * 4 * 2) * 64 + lane;     // its activation tiles
-    for (int kb = 0; kb < p.Kb; kb++) {
-        const int buf = kb & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies of step kb have landed
-        __syncthreads();                                    // ... everybody's; and step kb-1 has been read by all
-        if (kb + 1 < p.Kb) stage(kb + 1, buf ^ 1);
-        const h8_t* bw = lw + buf * (PF_STAGE_HALVES / 8);
-        const h8_t* ba = la + buf * (PF_STAGE_HALVES / 8);
-        h8_t wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) wf[i] = bw[i * 64];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const h8_t ah = ba[(2 * j) * 64], al = ba[(2 * j + 1) * 64];
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], ah, acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], al, acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue, straight from the accumulators.  acc[i][j] of lane l: token
-    // t = (tb0 + wc*4 + j)*16 + (l & 15), features n .. n+3 with n = nb*16 + 4*(l >> 4),
-    // nb = nb0 + wr*4 + i.
-    __syncthreads();   // s_rinv written before the loop is visible to all (also when Kb == 0)
+// The epilogues of gemm.hip applied to NI x NJ accumulator tiles of one wave.  v[i][j] of
+// lane l: token t = (tb0 + tbl_first + j)*16 + (l & 15), features n .. n+3 with
+// n = nb*16 + 4*(l >> 4), nb = nb_first + i.
+template <int NI, int NJ, int EPI, typename KVT>
+__device__ __forceinline__ void pf_epilogue(const GemmArgs& p, const f4_t (&v)[NI][NJ], int nb_first, int tbl_first, int tb0,
+                                            const float* s_rinv, int lane) {
     const GemmEpilogue& ep = p.e;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int tbj = tb0 + wc * 4 + j;
-        const int tl = (wc * 4 + j) * 16 + (lane & 15);
+    for (int j = 0; j < NJ; j++) {
+        const int tbj = tb0 + tbl_first + j;
+        const int tl = (tbl_first + j) * 16 + (lane & 15);
         const int t = tb0 * 16 + tl;
         const bool tok_live = t < p.T && tbj < p.Tb;
         const float rinv = ep.ss_in ? s_rinv[tl] : 1.0f;
@@ -142,13 +113,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_prefill(GemmArgs p, int tiles_n
             pos = ep.pos[t];
             kv_row = ep.kv_row[t];
         }
-        float ssq[2] = {0.f, 0.f};
+        float ssq[NI / 2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int nb = nb0 + wr * 4 + i;
+        for (int h = 0; h < NI / 2; h++) ssq[h] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int nb = nb_first + i;
             const int n = nb * 16 + 4 * (lane >> 4);
             const bool live = tok_live && nb < p.NB;
-            float y[4] = {acc[i][j][0] * rinv, acc[i][j][1] * rinv, acc[i][j][2] * rinv, acc[i][j][3] * rinv};
+            float y[4] = {v[i][j][0] * rinv, v[i][j][1] * rinv, v[i][j][2] * rinv, v[i][j][3] * rinv};
             if (EPI == GemmEpilogue::F32) {
                 if (live) {
                     float* o = ep.out + (size_t)t * ep.ldo + n;
@@ -161,11 +134,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_prefill(GemmArgs p, int tiles_n
                     }
                 }
             } else if (EPI == GemmEpilogue::SWIGLU_A16) {
-                // row blocks alternate gate (even), up (odd): i = 0,2 are gates, i+1 their ups
+                // row blocks alternate gate (even), up (odd); nb_first is even, so even i are gates
                 if ((i & 1) == 0 && live) {
                     float z[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], acc[(i + 1) & 3][j][r] * rinv);
+                    for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], v[(i + 1) % NI][j][r] * rinv);
                     const int hid = (nb >> 1) * 16 + 4 * (lane >> 4);
                     store_a16_4(ep.a16_out, ep.Kb_out, t, hid, z);
                 }
@@ -218,33 +191,188 @@ __global__ __launch_bounds__(256, 2) void k_gemm_prefill(GemmArgs p, int tiles_n
             // x four lane groups
             const int ss_cols = (p.N + 31) >> 5;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int h = 0; h < NI / 2; h++) {
                 float sq = ssq[h];
                 sq += __shfl_xor(sq, 16, 64);
                 sq += __shfl_xor(sq, 32, 64);
-                const int col = (nb0 + wr * 4 + 2 * h) >> 1;
+                const int col = (nb_first + 2 * h) >> 1;
                 if (lane < 16 && tok_live && col < ss_cols) ep.ss_out[(size_t)t * ss_cols + col] = sq;
             }
         }
     }
 }
 
-template <typename KVT>
-void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t) {
-    const dim3 grid(tiles_n * tiles_t), block(256);
+template <int FW, int KG, int EPI, typename KVT>
+__global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int tiles_n, int tiles_t, int nbuf) {
+    using G = PfGeom<FW, KG>;
+    // all LDS is one object: 128 floats of 1/rms, then the ring [nbuf][STAGE_TILES][512 halves]
+    extern __shared__ __attribute__((aligned(16))) __half lds_all[];
+    float* s_rinv = reinterpret_cast<float*>(lds_all);
+    __half* lds = lds_all + G::RINV_HALVES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = wave >> 2;                         // which K-steps of a stage this wave multiplies
+    const int wr = (wave >> 1) & 1, wc = wave & 1;    // its FW*16 features x 64 tokens inside the tile
+
+    // Workgroups are dealt round-robin to the 8 XCDs.  Give every XCD a contiguous range
+    // of the (feature tile, token tile) sequence, token tiles fastest: the workgroups that
+    // run together behind one L2 then share a few weight tiles and all walk the same
+    // activations.
+    const int total = tiles_n * tiles_t;
+    int id = blockIdx.x;
+    {
+        const int xcd = id & 7, slot = id >> 3;
+        const int q = total >> 3, r = total & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int nb0 = (id / tiles_t) * G::FB;
+    const int tb0 = (id % tiles_t) * G::TB;
+
+    // ---- who copies what: tile q of a stage belongs to K-step q / TPK of the stage and is
+    // weight block r (r < FB) or activation (block, plane) of r - FB, r = q % TPK; wave w
+    // copies tiles w*CPW .. w*CPW + CPW-1.  Every wave issues exactly CPW copies per stage
+    // (a K-step past the end repeats the last one), so the counted waits hold for all.
+    const __half* src[G::CPW];
+    int step[G::CPW], kofs[G::CPW];
+#pragma unroll
+    for (int u = 0; u < G::CPW; u++) {
+        const int q = wave * G::CPW + u;
+        const int r = q % G::TPK;
+        kofs[u] = q / G::TPK;
+        if (r < G::FB) {
+            src[u] = p.W + (size_t)min(nb0 + r, p.NB - 1) * p.nb_stride + lane * 8;
+            step[u] = TILE_HALVES;
+        } else {
+            const int tb = min(tb0 + ((r - G::FB) >> 1), p.Tb - 1);
+            src[u] = p.A + ((size_t)tb * p.Kb * 2 + ((r - G::FB) & 1)) * TILE_HALVES + lane * 8;
+            step[u] = 2 * TILE_HALVES;
+        }
+    }
+    const unsigned lds_tiles = (unsigned)(size_t)(lds_void*)lds + (unsigned)(wave * G::CPW) * (TILE_HALVES * 2);   // byte address in LDS
+    auto stage = [&](int s, int buf) {
+#pragma unroll
+        for (int u = 0; u < G::CPW; u++) {
+            const int kb = min(s * KG + kofs[u], p.Kb - 1);
+            copy_tile_to_lds(src[u] + (size_t)kb * step[u], lds_tiles + (unsigned)(buf * G::STAGE_TILES + u) * (TILE_HALVES * 2));
+        }
+    };
+
+    f4_t acc[FW][4];
+#pragma unroll
+    for (int i = 0; i < FW; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // 1/rms of the tile's tokens from the producer's sums of squares (two threads per token);
+    // done before the first copy is issued, so that its barrier does not wait for copies
+    if (p.e.ss_in != nullptr) {
+        const int tl = threadIdx.x & 127, part = threadIdx.x >> 7;
+        float ss = 0.f;
+        if (part < 2) {
+            const int t = min(tb0 * 16 + tl, p.T - 1);
+            const int srow = p.e.ss_gather ? p.e.ss_gather[t] : t;
+            const float* sp = p.e.ss_in + (size_t)srow * p.e.ss_tiles;
+            for (int j = part; j < p.e.ss_tiles; j += 2) ss += sp[j];
+        }
+        // the two halves meet in the result array itself: the upper half writes, the lower adds
+        if (part == 1) s_rinv[tl] = ss;
+        __syncthreads();
+        if (part == 0) s_rinv[tl] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss + s_rinv[tl], (float)p.e.d_in), p.e.eps)));
+    }
+
+    const int n_stages = (p.Kb + KG - 1) / KG;
+    const int ahead = nbuf - 1;   // stages in flight beyond the one being multiplied
+    for (int s0 = 0; s0 < ahead && s0 < n_stages; s0++) stage(s0, s0);
+
+    const h8_t* lw = reinterpret_cast<const h8_t*>(lds) + (kg * G::TPK + wr * FW) * 64 + lane;             // weight tiles of this wave
+    const h8_t* la = reinterpret_cast<const h8_t*>(lds) + (kg * G::TPK + G::FB + wc * 4 * 2) * 64 + lane;  // its activation tiles
+    int rb = 0;               // buffer of stage s
+    int wb = ahead % nbuf;    // buffer of stage s + ahead (= the one read at stage s - 1)
+    for (int s = 0; s < n_stages; s++) {
+        // this wave's copies of stage s have landed; the stages issued after it may still fly
+        wait_copies_but<G::CPW>(min(ahead - 1, n_stages - 1 - s));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's copies of stage s; and everybody is done reading stage s - 1
+        asm volatile("" ::: "memory");
+        if (s + ahead < n_stages) stage(s + ahead, wb);
+        if (KG == 1 || s * KG + kg < p.Kb) {
+            const h8_t* bw = lw + rb * (G::STAGE_HALVES / 8);
+            const h8_t* ba = la + rb * (G::STAGE_HALVES / 8);
+            h8_t wf[FW];
+#pragma unroll
+            for (int i = 0; i < FW; i++) wf[i] = bw[i * 64];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const h8_t ah = ba[(2 * j) * 64], al = ba[(2 * j + 1) * 64];
+#pragma unroll
+                for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], al, acc[i][j], 0, 0, 0);
+            }
+        }
+        rb = rb + 1 == nbuf ? 0 : rb + 1;
+        wb = wb + 1 == nbuf ? 0 : wb + 1;
+    }
+    __syncthreads();   // the ring is free; s_rinv (written by a quarter of the threads) is visible
+
+    if (KG == 1) {
+        pf_epilogue<FW, 4, EPI, KVT>(p, acc, nb0 + wr * FW, wc * 4, tb0, s_rinv, lane);
+    } else {
+        // The two wave groups hold the sums over the even and the odd K-steps of the same
+        // outputs.  Each wave keeps two of its four token blocks and hands the other two to
+        // its partner (same wr, wc in the other group) through the ring's memory.
+        f4_t* xch = reinterpret_cast<f4_t*>(lds);                  // [wave][FW][2][64]
+        f4_t* mine = xch + (size_t)wave * (FW * 2 * 64) + lane;
+        const f4_t* theirs = xch + (size_t)(wave ^ 4) * (FW * 2 * 64) + lane;
+        f4_t fin[FW][2];
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < FW; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) mine[(i * 2 + jj) * 64] = acc[i][2 + jj];
+        } else {
+#pragma unroll
+            for (int i = 0; i < FW; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) mine[(i * 2 + jj) * 64] = acc[i][jj];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < FW; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) fin[i][jj] = acc[i][jj] + theirs[(i * 2 + jj) * 64];
+        } else {
+#pragma unroll
+            for (int i = 0; i < FW; i++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) fin[i][jj] = theirs[(i * 2 + jj) * 64] + acc[i][2 + jj];
+        }
+        pf_epilogue<FW, 2, EPI, KVT>(p, fin, nb0 + wr * FW, wc * 4 + kg * 2, tb0, s_rinv, lane);
+    }
+}
+
+template <int FW, int KG, int EPI, typename KVT>
+void launch_one(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
+    using G = PfGeom<FW, KG>;
+    const size_t shmem = (size_t)(G::RINV_HALVES + nbuf * G::STAGE_HALVES) * sizeof(__half);
+    static size_t allowed = 0;   // per instantiation: the largest dynamic LDS size enabled so far
+    if (shmem > allowed) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_prefill<FW, KG, EPI, KVT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        allowed = shmem;
+    }
+    NVLLM_LAUNCH((k_gemm_prefill<FW, KG, EPI, KVT>), dim3(tiles_n * tiles_t), dim3(256 * KG), shmem, a, tiles_n, tiles_t, nbuf);
+}
+
+template <int FW, int KG, typename KVT>
+void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
     switch (a.e.kind) {
-        case GemmEpilogue::F32:
-            NVLLM_LAUNCH((k_gemm_prefill<GemmEpilogue::F32, KVT>), grid, block, 0, a, tiles_n, tiles_t);
-            break;
-        case GemmEpilogue::SWIGLU_A16:
-            NVLLM_LAUNCH((k_gemm_prefill<GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, a, tiles_n, tiles_t);
-            break;
-        case GemmEpilogue::RESID_A16:
-            NVLLM_LAUNCH((k_gemm_prefill<GemmEpilogue::RESID_A16, KVT>), grid, block, 0, a, tiles_n, tiles_t);
-            break;
-        default:
-            NVLLM_LAUNCH((k_gemm_prefill<GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, a, tiles_n, tiles_t);
-            break;
+        case GemmEpilogue::F32: launch_one<FW, KG, GemmEpilogue::F32, KVT>(a, tiles_n, tiles_t, nbuf); break;
+        case GemmEpilogue::SWIGLU_A16: launch_one<FW, KG, GemmEpilogue::SWIGLU_A16, KVT>(a, tiles_n, tiles_t, nbuf); break;
+        case GemmEpilogue::RESID_A16: launch_one<FW, KG, GemmEpilogue::RESID_A16, KVT>(a, tiles_n, tiles_t, nbuf); break;
+        default: launch_one<FW, KG, GemmEpilogue::ROPE_KV, KVT>(a, tiles_n, tiles_t, nbuf); break;
     }
 }
 
@@ -254,9 +382,31 @@ void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t) {
 void launch_gemm_prefill(GemmArgs a) {
     a.ksplit = 1;
     a.kb_per_split = a.Kb;
-    const int tiles_n = cdiv(a.NB, PF_FB), tiles_t = cdiv(a.Tb, PF_TB);
-    if (a.e.kind == GemmEpilogue::ROPE_KV && a.e.kv_elem_bytes == 2) launch_pf<__half>(a, tiles_n, tiles_t);
-    else launch_pf<float>(a, tiles_n, tiles_t);
+    const int tiles_t = cdiv(a.Tb, 8);
+    const int cus = rt().num_cus;
+    static const int shape_env = getenv("NVLLM_GEMM_PREFILL_SHAPE") ? atoi(getenv("NVLLM_GEMM_PREFILL_SHAPE")) : 0;   // 2: 8 waves, 3: 4 waves
+    static const int ring_env = getenv("NVLLM_GEMM_PREFILL_RING") ? atoi(getenv("NVLLM_GEMM_PREFILL_RING")) : 0;
+    const bool kv16 = a.e.kind == GemmEpilogue::ROPE_KV && a.e.kv_elem_bytes == 2;
+    const int wgs128 = cdiv(a.NB, 8) * tiles_t;
+    // 128-feature tiles.  When they all fit the chip at one per CU: eight waves per
+    // workgroup.  Otherwise four waves and as deep a ring as the co-resident workgroups
+    // leave room for (the hardware hands a CU its next workgroup as one finishes).
+    int shape = wgs128 <= cus ? 2 : 3;
+    if (shape_env) shape = shape_env;
+    if (shape == 2) {          // 48 KiB per stage (two K-steps); a ring of three fills the LDS
+        const int tiles_n = cdiv(a.NB, 8);
+        int nbuf = 3;
+        if (ring_env >= 2 && ring_env <= 3) nbuf = ring_env;
+        if (kv16) launch_pf<4, 2, __half>(a, tiles_n, tiles_t, nbuf);
+        else launch_pf<4, 2, float>(a, tiles_n, tiles_t, nbuf);
+    } else {                   // 24 KiB per stage
+        const int tiles_n = cdiv(a.NB, 8);
+        const int per_cu = cdiv(wgs128, cus);
+        int nbuf = per_cu >= 3 ? 2 : (per_cu == 2 ? 3 : 5);
+        if (ring_env >= 2 && ring_env <= 5) nbuf = ring_env;
+        if (kv16) launch_pf<4, 1, __half>(a, tiles_n, tiles_t, nbuf);
+        else launch_pf<4, 1, float>(a, tiles_n, tiles_t, nbuf);
+    }
 }
 
 }  // namespace nvllm
