@@ -211,6 +211,47 @@ def test_fp16_pool_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
         po.close()
 
 
+@pytest.mark.parametrize("hd,H,KVH", [(64, 32, 4), (48, 6, 6), (128, 8, 2)])
+def test_fp16_pool_attention_over_prefill_chunks(hip, oracle, hd, H, KVH):
+    """Hundreds of tokens per call (chunks of several sequences at different depths plus decode
+    rows): thousands of (token run, head group) items, the regime in which a workgroup takes
+    four consecutive items, one per wave."""
+    r = rng(hd * 7 + H)
+    L, bs, S = 1, 16, 1024
+    # (first position, tokens) per sequence: chunks that start mid-sequence, one whole prompt, decode rows
+    spans = [(300, 400), (0, 333), (700, 250), (512, 1), (17, 1), (1000, 24)]
+    n_seqs, maxb = len(spans), S // bs
+    nb = sum((p0 + n + bs - 1) // bs for p0, n in spans) + 3
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+        perm = r.permutation(nb)
+        cur = 0
+        for s_, (p0, n) in enumerate(spans):
+            need = (p0 + n + bs - 1) // bs
+            blocks = perm[cur:cur + need].tolist()
+            cur += need
+            ph.set_table(s_, blocks)
+            po.set_table(s_, blocks)
+        h16 = lambda a: a.astype(np.float16).astype(np.float32)
+        kfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        vfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        ph.fill(kfill, vfill)
+        po.fill(kfill, vfill)
+        pos = [p for p0, n in spans for p in range(p0, p0 + n)]
+        sid = [s_ for s_, (p0, n) in enumerate(spans) for _ in range(n)]
+        T = len(pos)
+        assert T > 1000
+        q = r.standard_normal((T, H * hd)).astype(np.float32)
+        want = util.op_paged_attention_batch(oracle, po, q, 0, pos, sid, S, H, KVH, hd)
+        got = util.op_paged_attention_batch(hip, ph, q, 0, pos, sid, S, H, KVH, hd)
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.abs(want).max() + 2e-6)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(4)
+        ph.close()
+        po.close()
+
+
 def test_kv_write_table_too_small_stops(hip, oracle, capfd):
     """Reference attention.c:159-162: the first token whose logical block is not in
     the table prints and ends the call; later tokens are not written."""
