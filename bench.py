@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak
 PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
 
 
@@ -60,6 +61,20 @@ def algorithmic_bytes_per_decode_step(shape, batch, ctx_lens, kv_bytes, tp_world
     kv_read = sum(c + 1 for c in ctx_lens) * kv_row
     kv_write = batch * kv_row
     return weights + kv_read + kv_write + batch * (D * 2 + 8)
+
+
+def prefill_roofline(shape, tokens_per_s, tp_world=1):
+    """Prefill is bound by the matrix cores: flops of the projections per token (2 per weight)
+    against the dense fp16 peak.  Activations enter as fp16 hi + lo, so the matrix cores
+    issue twice the useful flops; `frac` prices the issued ones (whole-job rate over all GPUs
+    that share one model under --tp, per replica otherwise)."""
+    D, F, L = shape.dim, shape.hidden_dim, shape.n_layers
+    QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
+    flops_per_token = 2.0 * L * (2 * D * QD + 2 * D * KD + 3 * D * F)
+    useful = flops_per_token * tokens_per_s / 1e12
+    return dict(bound="mfma", achieved=round(useful, 1), issued=round(2 * useful, 1), peak=MFMA_PEAK_TFLOPS * tp_world,
+                unit="TFLOP/s", frac=round(2 * useful / (MFMA_PEAK_TFLOPS * tp_world), 4),
+                note="projection flops only; tokens/s includes attention, host scheduling and the decode rows batched with the chunks")
 
 
 class DistEnv:
@@ -348,6 +363,7 @@ def main():
             "step_hbm": {"algorithmic_bytes_per_step": int(r["step_bytes"]), "achieved_GBps": round(step_gbs, 1),
                          "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
             "prefill_tokens_per_s": round(prefill_tps, 1),
+            "prefill_roofline": prefill_roofline(shape, prefill_tps, env.world if args.tp else 1),
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2),
                             "GBps": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in r["prof"].items()},
         }
