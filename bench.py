@@ -162,7 +162,7 @@ def run_gpu(args, env, shape, model_path):
     lib = capi.load_hip()           # raises if the HIP library is not built: no fall-back
     lib.nvllm_set_device(env.local_rank)
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
-    lib.nvllm_set_logits_mode(1)    # only token ids return to the host
+    lib.nvllm_set_logits_mode(0 if args.logits_host else 1)   # default: only token ids return to the host
     if args.tp:
         # one RCCL communicator over all ranks, owned by the library: its all-reduces run on the
         # library's stream.  (With one rank the same code path runs, the sums have one term.)
@@ -292,6 +292,9 @@ def main():
     ap.add_argument("--max-seq-len", type=int, default=None)
     ap.add_argument("--kv-bytes", type=int, default=2, choices=(2, 4),
                     help="KV pool element size: 2 = fp16 pages (default; parity covered by the fp16-pool GPU tests), 4 = the reference's fp32 rows")
+    ap.add_argument("--logits-host", action="store_true",
+                    help="copy the full fp32 logits rows to the host every step, as the reference's contract has it "
+                         "(the PCIe-inclusive variant; not the headline number)")
     ap.add_argument("--profile-steps", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
@@ -356,7 +359,8 @@ def main():
                                    f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
                                    f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
                                    f"mean context {r['ctx']} in the timed region",
-                       "batch_per_gpu": B, "parallelism": f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes},
+                       "batch_per_gpu": B, "parallelism": f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes,
+                       "result_handoff": "logits rows to host (PCIe-inclusive)" if args.logits_host else "token ids only"},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
             "cpu_baseline": cpu,
