@@ -259,3 +259,31 @@ def test_prefill_batches_of_hundreds_of_tokens(hip, oracle, tmp_models, kv_bytes
         hip.nvllm_set_kv_elem_bytes(before)
     worst = _compare_runs(g, o)
     assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), worst
+
+
+def test_unmodified_reference_driver_runs_on_the_gpu(tmp_path):
+    """The reference's own main() -- its scheduler loop, tokenizer, sampler, dashboards, compiled
+    unmodified (oracle/_ref/nano_vllm_hip, built where /root/reference exists) and linked with
+    libnvllm_hip.so -- against the reference's own CPU binary on the same model and tokenizer
+    files: the generated text of both sequences must be byte-identical (2-sequence demo, paged,
+    chunked prefill, greedy)."""
+    import os
+    import subprocess
+    ref_dir = os.path.dirname(capi.REF_LIB)
+    exe_hip, exe_ref = os.path.join(ref_dir, "nano_vllm_hip"), os.path.join(ref_dir, "nano_vllm_ref")
+    if not (os.path.exists(exe_hip) and os.path.exists(exe_ref)):
+        pytest.skip("oracle/_ref demo binaries not built (they need /root/reference at build time)")
+    shape = synth.ModelShape.named("stories15M", vocab_size=512, max_seq_len=256)
+    synth.write_model(str(tmp_path / "model.bin"), shape, seed=33)
+    synth.write_tokenizer(str(tmp_path / "tokenizer.bin"), shape.vocab_size)
+    outs = {}
+    for name, exe in (("ref", exe_ref), ("hip", exe_hip)):
+        r = subprocess.run([exe, str(tmp_path / "model.bin"), "-t", "0", "-n", "40", "--paged", "--chunk-size", "16"],
+                           cwd=str(tmp_path), capture_output=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        out = r.stdout
+        assert b"=== Final Generated Sequences ===" in out, (name, out[-2000:])
+        tail = out[out.index(b"=== Final Generated Sequences ==="):]
+        outs[name] = tail[:tail.index(b"\n=================================")]
+    assert b"[Seq 0]: " in outs["ref"] and b"[Seq 1]: " in outs["ref"]
+    assert outs["hip"] == outs["ref"]
