@@ -304,6 +304,12 @@ def main():
         if getattr(args, name) is None:
             setattr(args, name, val)
 
+    # stdout carries exactly ONE line (the JSON below): whatever libraries print on the way
+    # (RCCL's version banner, loader messages) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from nvllm_amd import synth
     env = DistEnv(args.gpus)
     shape = synth.ModelShape.named(args.model, max_seq_len=args.max_seq_len)
@@ -371,7 +377,10 @@ def main():
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2),
                             "GBps": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in r["prof"].items()},
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     env.close()
 
 

@@ -72,7 +72,9 @@ void nvllm_prof_get(int cls, long long* launches, double* total_ms, double* byte
  * n_heads/world attention heads (whole kv heads with their query heads) and
  * hidden_dim/world columns of the MLP, and the partial results of the two projections
  * that return to the residual width are summed over the ranks -- after the wo
- * projection (src/model.c:385) and after w_down (src/model.c:392).  All ranks must
+ * projection (src/model.c:385) and after w_down (src/model.c:392); the classifier
+ * (src/model.c:411-418) is split by vocabulary rows and the ranks gather arg-max pairs
+ * or logits slices.  All ranks must
  * issue identical calls with identical arguments (same model file, requests, block
  * tables); Config, RunState and the block tables keep their full-model meaning, the
  * weight handles in `Weights` and the KV pool cover this rank's slice only.
@@ -82,6 +84,8 @@ typedef struct {
     int n_heads, head0;        /* query heads of this rank: [head0, head0 + n_heads)        */
     int n_kv_heads, kv_head0;  /* kv heads of this rank                                     */
     int hidden, hidden0;       /* columns of the hidden activation: [hidden0, hidden0+hidden) */
+    int vocab, vocab0;         /* classifier rows [vocab0, vocab0 + vocab); may be empty      */
+    int vocab_slice;           /* rows per rank before clipping (a multiple of 16)            */
 } NvllmTpShard;
 /* The slice rank `rank` of `world` owns for this model shape.  0, or -1 when the shape
  * does not divide (kv heads and heads by world, hidden_dim by 32*world). */

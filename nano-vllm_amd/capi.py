@@ -58,7 +58,8 @@ class Sampler(C.Structure):
 
 
 class TpShard(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("rank", "world", "n_heads", "head0", "n_kv_heads", "kv_head0", "hidden", "hidden0")]
+    _fields_ = [(n, C.c_int) for n in ("rank", "world", "n_heads", "head0", "n_kv_heads", "kv_head0", "hidden", "hidden0",
+                                         "vocab", "vocab0", "vocab_slice")]
 
 
 # void fn(void* ctx, float* device_buf, size_t count, void* hip_stream)

@@ -425,10 +425,13 @@ void launch_softmax(float* x, int n) {
 
 // First index of the row maximum (reference sampler.c:86-97: strict '>' scan, so
 // ties resolve to the lowest index).
-__global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const float* __restrict__ logits, int V) {
+// `pairs` (optional): instead of the index, (maximum, index_base + index as a float) per row --
+// what a tensor-parallel rank contributes for its slice of the vocabulary.
+__global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const float* __restrict__ logits, int V, int ld,
+                                                 float2* __restrict__ pairs, int index_base) {
     __shared__ float sv[16];
     __shared__ int si[16];
-    const float* row = logits + (size_t)blockIdx.x * V;
+    const float* row = logits + (size_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
     auto take = [&](float v, int i) {
@@ -485,13 +488,53 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
                 bi = si[w];
             }
         // a row of -inf (or NaN in slot 0) leaves the scan at index 0 in the reference
-        out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+        const int idx = bi == 0x7fffffff ? 0 : bi;
+        if (pairs) pairs[blockIdx.x] = make_float2(V > 0 ? best : -INFINITY, (float)(index_base + idx));
+        else out[blockIdx.x] = idx;
     }
 }
 void launch_argmax(int* out, const float* logits, int B, int V) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
-    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, V, (float2*)nullptr, 0);
+}
+void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)B * n_valid * 4.0, 0);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, (int*)nullptr, logits, n_valid, ld, pairs, index_base);
+}
+
+// The ranks' (maximum, index) pairs, gathered as [rank][row]: the overall arg-max, lowest index on
+// ties (ranks own ascending index ranges, so the first maximum in rank order is it).
+__global__ __launch_bounds__(256) void k_argmax_merge(int* __restrict__ out, const float2* __restrict__ pairs, int W, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float2 best = pairs[b];
+    for (int r = 1; r < W; r++) {
+        const float2 c = pairs[(size_t)r * B + b];
+        if (c.x > best.x) best = c;
+    }
+    out[b] = (int)best.y;
+}
+void launch_argmax_merge(int* out, const float2* pairs, int W, int B) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)W * B * 8.0, 0);
+    NVLLM_LAUNCH(k_argmax_merge, dim3(cdiv(B, 256)), dim3(256), 0, out, pairs, W, B);
+}
+
+// Vocabulary slices gathered as [rank][row][Vl] -> logits [row][V]
+__global__ __launch_bounds__(256) void k_logits_unshard(float* __restrict__ full, const float* __restrict__ parts, int W, int B,
+                                                        int Vl, int V) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const int r = i / Vl, c = i - r * Vl;
+        full[(size_t)b * V + i] = parts[((size_t)r * B + b) * Vl + c];
+    }
+}
+void launch_logits_unshard(float* full, const float* parts, int W, int B, int Vl, int V) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ELEMWISE, (double)B * V * 8.0, 0);
+    NVLLM_LAUNCH(k_logits_unshard, dim3(cdiv(V, 256 * 4), B), dim3(256), 0, full, parts, W, B, Vl, V);
 }
 
 // Temperature softmax of each row plus the candidate filter of nucleus sampling

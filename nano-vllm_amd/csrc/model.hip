@@ -47,12 +47,25 @@ static const float* g_last_logits_host = nullptr;
 static const float* g_last_logits_dev = nullptr;
 static int g_last_vocab = 0;
 static long g_pass_serial = 0;         // bumped by every forward pass
+// tensor parallelism: the last pass left only this rank's vocabulary slice (arg-max hand-off);
+// sample() with a temperature gathers the full rows when it needs them
+static const float* g_tp_local = nullptr;
+static bool g_tp_full_valid = true;
+static int g_tp_slice = 0;
 
 static void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
     if (fread(dst, 1, bytes, f) != bytes) {
         fprintf(stderr, "Failed to read %s from file (expected %zu bytes)\n", what, bytes);
         exit(1);
     }
+}
+
+// every rank's slice [rows, slice] -> full logits rows [rows, V] on every rank
+static void tp_gather_logits(float* full, const float* local, int rows, int slice, int V) {
+    const int W = tp().world;
+    float* parts = (float*)ws_get(WS_TP_GATHER, (size_t)W * rows * slice * sizeof(float));
+    tp_allgather(local, parts, (size_t)rows * slice);
+    launch_logits_unshard(full, parts, W, rows, slice, V);
 }
 
 }  // namespace nvllm
@@ -123,7 +136,8 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     const size_t t_wo = (size_t)(D / 16) * Kb_QD * TILE_HALVES * 2;
     const size_t t_gu = (size_t)(2 * Fl / 16) * Kb_D * TILE_HALVES * 2;
     const size_t t_dn = (size_t)(D / 16) * Kb_F * TILE_HALVES * 2;
-    const size_t t_head = (size_t)((V + 15) / 16) * Kb_D * TILE_HALVES * 2;
+    const long long Vh = tp().world > 1 ? sh.vocab : V, v0 = tp().world > 1 ? sh.vocab0 : 0;   // classifier rows held here
+    const size_t t_head = (size_t)((Vh + 15) / 16 + 1) * Kb_D * TILE_HALVES * 2;
     const size_t per_layer = align(t_qkv) + align(t_wo) + align(t_gu) + align(t_dn) + 2 * align(D * 4);
     const size_t total = align(V * D * 2) + L * per_layer + align(D * 4) + align(t_head);
     if (device_malloc(&m->arena, total) != 0) NVLLM_FATAL("cannot allocate %zu bytes of HBM for the weights", total);
@@ -190,15 +204,15 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
         else launch_f16_to_f32((float*)dst, (const __half*)stage, n);
         HIP_CHECK(hipStreamSynchronize(st));
     };
-    auto tile_into = [&](const __half* dst, long long rows, long long K, long nb_stride) {
-        launch_tile_weights(const_cast<__half*>(dst), stage16, (int)rows, (int)K, nb_stride);
+    auto tile_into = [&](const __half* dst, long long rows, long long K, long nb_stride, long long first_row = 0) {
+        if (rows > 0) launch_tile_weights(const_cast<__half*>(dst), stage16 + first_row * K, (int)rows, (int)K, nb_stride);
         HIP_CHECK(hipStreamSynchronize(st));
     };
     const long str_D = (long)Kb_D * TILE_HALVES, str_QD = (long)Kb_QD * TILE_HALVES, str_F = (long)Kb_F * TILE_HALVES;
 
     fetch(V * D, "token_embedding_table");
     HIP_CHECK(hipMemcpyAsync((void*)m->embed, stage16, V * D * 2, hipMemcpyDeviceToDevice, st));
-    if (shared) tile_into(m->head, V, D, str_D);
+    if (shared) tile_into(m->head, Vh, D, str_D, v0);
     HIP_CHECK(hipStreamSynchronize(st));
     for (int l = 0; l < L; l++) fetch_vec(m->layers[l].rms_att, D, "rms_att_weight");
     for (int l = 0; l < L; l++) { fetch_rows(QD, D, q0, QDl, "wq"); tile_into(m->layers[l].qkv, QDl, D, str_D); }
@@ -210,7 +224,7 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     for (int l = 0; l < L; l++) { fetch_cols(D, F, f0, Fl, "w_down"); tile_into(m->layers[l].down, D, Fl, str_F); }  // file order: down before up (model.c:262-269)
     for (int l = 0; l < L; l++) { fetch_rows(F, D, f0, Fl, "w_up"); tile_into(m->layers[l].gateup + str_D, Fl, D, 2 * str_D); }
     fetch_vec(m->rms_final, D, "rms_final_weight");
-    if (!shared) { fetch(V * D, "lm_head"); tile_into(m->head, V, D, str_D); }
+    if (!shared) { fetch_rows(V, D, v0, Vh, "lm_head"); tile_into(m->head, Vh, D, str_D); }
     fclose(f);
     free(host);
     device_free(stage);
@@ -244,7 +258,7 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     }
     w->token_embedding_table = (float*)m->embed;
     w->rms_final_weight = (float*)m->rms_final;
-    w->lm_head = reg(m->head, V, D, str_D);
+    w->lm_head = reg(m->head, Vh, D, str_D);
     w->_data_buffer = m;
 }
 
@@ -420,14 +434,42 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         a16_head = g16;
         ss_head = gss;
     }
-    WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
     GemmEpilogue e5;
     e5.kind = GemmEpilogue::F32;
     e5.ss_in = ss_head; e5.ss_tiles = ssn; e5.d_in = D; e5.eps = eps;
-    e5.out = d_logits;
-    e5.ldo = V;
-    launch_gemm(wh, m->head, V, a16_head, B, e5, 1, PC_GEMM_HEAD);
-    launch_argmax(d_argmax, d_logits, B, V);
+    g_tp_full_valid = true;
+    if (!partial) {
+        WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
+        e5.out = d_logits;
+        e5.ldo = V;
+        launch_gemm(wh, m->head, V, a16_head, B, e5, 1, PC_GEMM_HEAD);
+        launch_argmax(d_argmax, d_logits, B, V);
+    } else {
+        // this rank's vocabulary rows; then either one (max, index) pair per row from every rank,
+        // or the slices themselves when full rows are wanted
+        const int W = tp().world, slice = m->sh.vocab_slice, mine = W > 1 ? m->sh.vocab : V, base = W > 1 ? m->sh.vocab0 : 0;
+        const int ld = W > 1 ? slice : V;
+        float* local = (float*)ws_get(WS_TP_LOCAL, ((size_t)B * ld + 2 * (size_t)B + 64) * sizeof(float));
+        if (mine > 0) {
+            WeightEntry wh{m->head, mine, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
+            e5.out = local;
+            e5.ldo = ld;
+            launch_gemm(wh, m->head, mine, a16_head, B, e5, 1, PC_GEMM_HEAD);
+        }
+        g_tp_local = local;
+        g_tp_slice = ld;
+        if (rt().logits_mode == NVLLM_LOGITS_ARGMAX) {
+            float2* pairs = (float2*)(local + (((size_t)B * ld + 1) & ~(size_t)1));
+            launch_argmax_pairs(pairs, local, B, mine, ld, base);
+            float2* all = (float2*)ws_get(WS_TP_GATHER, (size_t)W * B * sizeof(float2));
+            tp_allgather((const float*)pairs, (float*)all, 2 * (size_t)B);
+            launch_argmax_merge(d_argmax, all, W, B);
+            g_tp_full_valid = false;   // d_logits was not produced; sample() gathers it if it needs rows
+        } else {
+            tp_gather_logits(d_logits, local, B, ld, V);
+            launch_argmax(d_argmax, d_logits, B, V);
+        }
+    }
 
     if (B > g_argmax_cap) {
         if (g_argmax_host) HIP_CHECK(hipHostFree(g_argmax_host));
@@ -567,6 +609,10 @@ int sample(Sampler* s, float* logits) {
             const size_t d = (size_t)(logits - g_last_logits_host);
             if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) {
                 // a row of the most recent forward pass: its logits are still in HBM
+                if (!g_tp_full_valid) {   // ... as vocabulary slices on the ranks: every rank makes this call
+                    tp_gather_logits(const_cast<float*>(g_last_logits_dev), g_tp_local, g_last_outputs, g_tp_slice, V);
+                    g_tp_full_valid = true;
+                }
                 if (g_prep_serial != g_pass_serial || g_prep_temp != s->temperature || g_prep_topp != s->topp) {
                     prepare_rows(g_last_logits_dev, g_last_outputs, V, s->temperature, s->topp);
                     g_prep_serial = g_pass_serial;

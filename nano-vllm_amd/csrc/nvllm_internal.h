@@ -95,6 +95,8 @@ struct TpState {
 };
 TpState& tp();
 void tp_allreduce(float* buf, size_t count);   // in place, on the library stream
+// recv[r * count .. ) = rank r's `count` floats at send, on every rank (send must not overlap recv)
+void tp_allgather(const float* send, float* recv, size_t count);
 
 // Grow-only device scratch, one buffer per slot.
 enum WsSlot {
@@ -109,6 +111,8 @@ enum WsSlot {
     WS_MISC,
     WS_MISC2,
     WS_SAMPLE,      // a logits row handed to sample() that is not part of the last forward pass
+    WS_TP_LOCAL,    // tensor parallelism: this rank's slice of the logits / its arg-max pairs
+    WS_TP_GATHER,   // ... and what the ranks gathered
     WS_COUNT
 };
 void* ws_get(WsSlot slot, size_t bytes);
@@ -265,6 +269,11 @@ void launch_swiglu(float* out, const float* g, const float* u, long n);
 void launch_accum(float* a, const float* b, long n);
 void launch_softmax(float* x, int n);
 void launch_argmax(int* out, const float* logits, int B, int V);
+// tensor-parallel classifier: per-rank (max, global index) pairs, their merge, and the regrouping of
+// gathered vocabulary slices [rank][row][Vl] into logits rows [row][V]
+void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base);
+void launch_argmax_merge(int* out, const float2* pairs, int W, int B);
+void launch_logits_unshard(float* full, const float* parts, int W, int B, int Vl, int V);
 // probs = softmax(logits / temperature) per row; cutoff >= 0 also compacts the entries >= cutoff, in
 // index order, into cand[row][0..cap) and counts them (count may exceed cap: the row did not fit)
 void launch_sample_prep(float* probs, const float* logits, int B, int V, float temperature, float cutoff,

@@ -4,11 +4,14 @@
 // wq/wk/wv that produce its heads and the rows of w_gate/w_up that produce its slice of
 // the hidden activation, together with the matching COLUMNS of wo and w_down.  Each
 // rank then holds a partial sum of the two projections that return to the residual
-// width, and those two partial sums per layer are the only data the ranks exchange: a
-// sum all-reduce of [tokens, dim] fp32 after wo (reference src/model.c:385) and after
-// w_down (src/model.c:392).  Everything else -- scheduler, block tables, allocator,
-// embedding, classifier, sampler -- runs replicated and deterministically on every
-// rank, so all ranks take the same decisions without talking.
+// width, and those two partial sums per layer are the only data the ranks exchange inside
+// the layers: a sum all-reduce of [tokens, dim] fp32 after wo (reference src/model.c:385)
+// and after w_down (src/model.c:392).  The classifier is split by vocabulary rows: every
+// rank computes the logits of its slice and the ranks gather either one (maximum, index)
+// pair per output row (arg-max hand-off) or the slices themselves (logits for the host or
+// for sampling).  Everything else -- scheduler, block tables, allocator, embedding,
+// sampler -- runs replicated and deterministically on every rank, so all ranks take the
+// same decisions without talking.
 //
 // The all-reduce is enqueued on the library's own stream between the projection and
 // the kernel that adds the result to the residual, so no host synchronisation is
@@ -30,6 +33,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -50,9 +54,10 @@ bool open_rccl() {
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(dl, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(dl, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(dl, "ncclAllReduce");
+    a.AllGather = (decltype(a.AllGather))dlsym(dl, "ncclAllGather");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(dl, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
-        fprintf(stderr, "nvllm: librccl lacks one of the five entry points used here\n");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather || !a.GetErrorString) {
+        fprintf(stderr, "nvllm: librccl lacks one of the six entry points used here\n");
         dlclose(dl);
         return false;
     }
@@ -83,6 +88,24 @@ void tp_allreduce(float* buf, size_t count) {
     RCCL_CHECK(g_rccl.AllReduce(buf, buf, count, ncclFloat32, ncclSum, g_comm, rt().stream));
 }
 
+void tp_allgather(const float* send, float* recv, size_t count) {
+    TpState& s = tp();
+    if (count == 0) return;
+    if (!s.active || (s.fn && s.world == 1)) {   // (a one-rank RCCL communicator still goes through RCCL)
+        HIP_CHECK(hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, rt().stream));
+        return;
+    }
+    if (s.fn) {
+        // a caller-supplied exchange only sums: gather = sum of slices padded with zeros
+        // (x + 0 is x for every float these buffers carry)
+        HIP_CHECK(hipMemsetAsync(recv, 0, (size_t)s.world * count * sizeof(float), rt().stream));
+        HIP_CHECK(hipMemcpyAsync(recv + (size_t)s.rank * count, send, count * sizeof(float), hipMemcpyDeviceToDevice, rt().stream));
+        s.fn(s.ctx, recv, (size_t)s.world * count, (void*)rt().stream);
+        return;
+    }
+    RCCL_CHECK(g_rccl.AllGather(send, recv, count, ncclFloat32, g_comm, rt().stream));
+}
+
 }  // namespace nvllm
 
 using namespace nvllm;
@@ -104,6 +127,11 @@ int nvllm_tp_shard(const Config* cfg, int rank, int world, NvllmTpShard* out) {
     out->kv_head0 = rank * out->n_kv_heads;
     out->hidden = cfg->hidden_dim / world;
     out->hidden0 = rank * out->hidden;
+    // classifier rows: equal slices of whole 16-row blocks; the last ranks may hold fewer (or none)
+    const int per = ((cfg->vocab_size + 15) / 16 + world - 1) / world * 16;
+    out->vocab_slice = per;
+    out->vocab0 = rank * per < cfg->vocab_size ? rank * per : cfg->vocab_size;
+    out->vocab = cfg->vocab_size - out->vocab0 < per ? cfg->vocab_size - out->vocab0 : per;
     if (world > 1 && ((out->n_heads * hd) % 32 || (out->n_kv_heads * hd) % 16)) return -1;
     return 0;
 }

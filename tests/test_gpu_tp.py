@@ -65,9 +65,36 @@ def test_rccl_communicator_of_one_rank(hip, oracle, tmp_models):
     assert hip.nvllm_tp_unique_id(ident) == 0
     assert hip.nvllm_tp_init(0, 1, ident) == 0
     try:
-        _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)
+        o = _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)      # ncclAllReduce + ncclAllGather of logits slices
+        hip.nvllm_set_logits_mode(1)                                   # ncclAllGather of (max, index) pairs
+        prompts = synth.make_requests(4, 3, 40, shape.vocab_size, seed=17)
+        g = util.run_engine(hip, path, prompts, n_new=20, arrivals=[0, 1, 1, 4], chunk_size=16, temperature=0.0, max_steps=400)
+        for a, b in zip(g["histories"], o["histories"]):
+            np.testing.assert_array_equal(a, b)
     finally:
+        hip.nvllm_set_logits_mode(0)
         hip.nvllm_tp_finalize()
+
+
+def test_vocabulary_split_hand_offs_with_a_single_rank(hip, oracle, tmp_models):
+    """The classifier path of the tensor-parallel forward pass (slice -> pairs -> merge, and
+    slice -> gathered rows for sampling) in one process."""
+    path, shape = tmp_models("tiny", seed=3, **GQA)
+    cb = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
+    prompts = synth.make_requests(3, 3, 30, shape.vocab_size, seed=29)
+    res = {}
+    for temperature in (0.0, 0.9):
+        kw = dict(n_new=14, chunk_size=16, temperature=temperature, topp=0.8, seed=5)
+        o = util.run_engine(oracle, path, prompts, **kw)
+        assert hip.nvllm_tp_init_custom(0, 1, cb, None) == 0
+        hip.nvllm_set_logits_mode(1)
+        try:
+            g = util.run_engine(hip, path, prompts, **kw)
+        finally:
+            hip.nvllm_set_logits_mode(0)
+            hip.nvllm_tp_finalize()
+        for a, b in zip(g["histories"], o["histories"]):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_setup_is_refused_twice_and_for_bad_placements(hip):
@@ -104,5 +131,9 @@ def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_
         r = json.load(open(tmp_path / f"rank{rank}.json"))
         assert r["same_trace"] and r["same_tokens"], r
         assert r["worst"] < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), r
-        assert r["allreduce_calls"] == 2 * r["n_layers"] * r["steps"]
-        assert r["allreduce_floats"] == 2 * r["n_layers"] * r["dim"] * r["tokens_forwarded"]
+        assert r["same_argmax"], r      # (max, index) pairs instead of logits rows
+        assert r["same_sampled"], r     # temperature / top-p from rows gathered on demand
+        # per step: two partial sums per layer, plus the gather of the logits slices (the test's
+        # exchange only sums, so a gather is a sum over zero-padded slices)
+        assert r["allreduce_calls"] == (2 * r["n_layers"] + 1) * r["steps"]
+        assert r["allreduce_floats"] == 2 * r["n_layers"] * r["dim"] * r["tokens_forwarded"] + world * r["vocab_slice"] * r["output_rows"]

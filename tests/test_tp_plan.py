@@ -44,6 +44,13 @@ def test_slices_partition_heads_and_hidden_columns(shard, shape, world):
         heads += range(s.head0, s.head0 + s.n_heads)
         kvs += range(s.kv_head0, s.kv_head0 + s.n_kv_heads)
         cols += range(s.hidden0, s.hidden0 + s.hidden)
+    rows = []
+    for rank in range(world):
+        _, s = shard(rank, world, **shape)
+        assert s.vocab_slice % 16 == 0 and 0 <= s.vocab <= s.vocab_slice
+        assert s.vocab0 == min(rank * s.vocab_slice, 32000)
+        rows += range(s.vocab0, s.vocab0 + s.vocab)
+    assert rows == list(range(32000))
     assert heads == list(range(shape["n_heads"]))
     assert kvs == list(range(shape["n_kv_heads"]))
     assert cols == list(range(shape["hidden_dim"]))

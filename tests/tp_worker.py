@@ -54,15 +54,34 @@ def main():
     assert hip.nvllm_tp_init_custom(rank, world, cb, None) == 0
     assert (hip.nvllm_tp_rank(), hip.nvllm_tp_world()) == (rank, world)
     got = util.run_engine(hip, path, prompts, **kw)
+    reduce_calls, reduce_floats = calls["n"], calls["floats"]
+    # arg-max hand-off: the ranks exchange one (max, index) pair per row instead of logits
+    hip.nvllm_set_logits_mode(1)
+    kw2 = dict(kw, collect_logits=False)
+    got_argmax = util.run_engine(hip, path, prompts, **kw2)
+    # temperature / top-p sampling from rows that exist only as vocabulary slices on the ranks
+    kw3 = dict(kw2, temperature=0.8, topp=0.9, seed=77)
+    want_sampled = util.run_engine(oracle, path, prompts, **kw3)
+    got_sampled = util.run_engine(hip, path, prompts, **kw3)
+    hip.nvllm_set_logits_mode(0)
     hip.nvllm_tp_finalize()
+    cfg = capi.Config(dim=shape.dim, hidden_dim=shape.hidden_dim, n_layers=shape.n_layers, n_heads=shape.n_heads,
+                      n_kv_heads=shape.n_kv_heads, vocab_size=shape.vocab_size, max_seq_len=shape.max_seq_len)
+    sh = capi.TpShard()
+    assert hip.nvllm_tp_shard(C.byref(cfg), rank, world, C.byref(sh)) == 0
 
     same_tokens = all(np.array_equal(a, b) for a, b in zip(got["histories"], want["histories"]))
     same_trace = np.array_equal(got["trace"], want["trace"])
     worst = max(float(np.abs(a["logits"] - b["logits"]).max()) for a, b in zip(got["steps"], want["steps"]))
     tokens_forwarded = int(sum(len(s["tokens"]) for s in want["steps"]))
+    same_argmax = all(np.array_equal(a, b) for a, b in zip(got_argmax["histories"], want["histories"]))
+    same_sampled = all(np.array_equal(a, b) for a, b in zip(got_sampled["histories"], want_sampled["histories"]))
+    rows = int(sum(len(s["output_indices"]) for s in want["steps"]))
     out = dict(rank=rank, world=world, same_tokens=bool(same_tokens), same_trace=bool(same_trace), worst=worst,
-               allreduce_calls=calls["n"], allreduce_floats=calls["floats"], steps=len(want["steps"]),
-               tokens_forwarded=tokens_forwarded, n_layers=shape.n_layers, dim=shape.dim)
+               same_argmax=bool(same_argmax), same_sampled=bool(same_sampled),
+               allreduce_calls=reduce_calls, allreduce_floats=reduce_floats, steps=len(want["steps"]),
+               tokens_forwarded=tokens_forwarded, n_layers=shape.n_layers, dim=shape.dim,
+               output_rows=rows, vocab_slice=sh.vocab_slice, vocab=[sh.vocab0, sh.vocab])
     with open(os.path.join(spec["out_dir"], f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
     dist.barrier()
