@@ -101,7 +101,8 @@ int nvllm_tp_init(int rank, int world, const void* id);
 /* The same with the exchange supplied by the caller: fn must leave the element-wise sum
  * over all ranks of the `count` floats at device_buf in device_buf on every rank,
  * ordered after the work already enqueued on hip_stream and before work enqueued
- * later (enqueue on that stream, or synchronise it). */
+ * later (enqueue on that stream, or synchronise it).  The library also builds its gathers
+ * from it (a sum over slices padded with zeros). */
 typedef void (*nvllm_allreduce_fn)(void* ctx, float* device_buf, size_t count, void* hip_stream);
 int nvllm_tp_init_custom(int rank, int world, nvllm_allreduce_fn fn, void* ctx);
 
