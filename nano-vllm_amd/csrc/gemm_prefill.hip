@@ -28,8 +28,8 @@
 // the step to the other waves and at the same time retires the buffer read one step
 // earlier, which is then refilled.  The ring depth follows the launch: a wide
 // projection makes several workgroups per CU, which cover each other's waits, so two
-// buffers (three workgroups fit a CU) are enough; a narrow one makes about one
-// workgroup per CU, which then keeps five steps in flight on its own.
+// buffers (three workgroups fit a CU) are enough; fewer workgroups per CU get deeper
+// rings (up to five buffers of 24 KiB, or three of 48 KiB in the 8-wave form).
 //
 // The epilogues are those of gemm.hip (F32, SWIGLU_A16, RESID_A16, ROPE_KV) applied
 // straight from the accumulators: a lane holds, per accumulator tile, four consecutive
@@ -92,7 +92,6 @@ __device__ __forceinline__ void wait_copies_but(int stages) {
         }
     }
 }
-
 
 // The epilogues of gemm.hip applied to NI x NJ accumulator tiles of one wave.  v[i][j] of
 // lane l: token t = (tb0 + tbl_first + j)*16 + (l & 15), features n .. n+3 with
