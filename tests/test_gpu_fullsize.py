@@ -39,9 +39,9 @@ def test_decode_batch_of_64_at_the_benchmark_shape(hip, oracle, tinyllama):
     (the benchmark's configuration)."""
     path, shape = tinyllama
     prompts = synth.make_requests(64, 2, 2, shape.vocab_size, seed=11)
-    kw = dict(n_new=4, collect_logits=True, chunk_size=512, temperature=0.0, max_steps=50)
+    kw = dict(n_new=10, collect_logits=True, chunk_size=512, temperature=0.0, max_steps=50)
     o = util.run_engine(oracle, path, prompts, **kw)
-    assert sum(len(s["tokens"]) == 64 for s in o["steps"]) >= 3     # the 64-row decode steps are in there
+    assert sum(len(s["tokens"]) == 64 for s in o["steps"]) >= 9     # the 64-row decode steps are in there
     before = hip.nvllm_get_kv_elem_bytes()
     hip.nvllm_set_kv_elem_bytes(2)
     try:
