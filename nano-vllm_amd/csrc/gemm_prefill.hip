@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
             h8_t wf[FW];
 #pragma unroll
             for (int i = 0; i < FW; i++) wf[i] = bw[i * 64];
+            __builtin_amdgcn_s_setprio(1);   // a wave that is multiplying keeps the issue slot over one that is copying
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const h8_t ah = ba[(2 * j) * 64], al = ba[(2 * j + 1) * 64];
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
 #pragma unroll
                 for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], al, acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         rb = rb + 1 == nbuf ? 0 : rb + 1;
         wb = wb + 1 == nbuf ? 0 : wb + 1;
