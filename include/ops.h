@@ -27,15 +27,29 @@ void init_ops(void);
 void free_ops(void);
 
 /* o[t,:] = x[t,:] * (1/sqrtf(mean(x[t,:]^2) + eps)) * weight[:]; o may alias x.
+ *   o, x    [num_tokens, size] fp32 in HBM          weight  [size] fp32 in HBM
+ * The sum of squares is taken in fp32 per row; the scaling is (x * r) * w in that
+ * order, as the reference rounds it.
  * Reference: src/kernels/layers.c:23-38. */
 void rms_norm(float* o, float* x, float* weight, int size, int num_tokens, float eps);
 
 /* out[t,i] = sum_j in[t,j] * weight[i,j]; weight is [out_dim, in_dim].
+ *   out     [num_tokens, out_dim] fp32 in HBM       in  [num_tokens, in_dim] fp32 in HBM
+ *   weight  either a plain fp32 [out_dim, in_dim] HBM buffer, or one of the pointers
+ *           load_model() stored in Weights / LayerWeights (fp16 tiles in HBM; the call
+ *           checks that in_dim / out_dim match the tensor behind the handle)
+ * fp32 accumulation on the matrix cores; the fp32 input enters as an fp16 pair
+ * (value, remainder), so products are formed as the reference forms them from fp16
+ * weights expanded to fp32, up to the order of the sum.
  * Reference: src/kernels/layers.c:44-67. */
 void matmul(float* out, float* in, float* weight, int num_tokens, int in_dim, int out_dim);
 
 /* Interleaved-pair rotary embedding on q (n_heads) and k (n_kv_heads), in place;
- * token t sits at position pos + t.  Reference: src/kernels/layers.c:73-107. */
+ * token t sits at position pos + t.
+ *   q  [num_tokens, n_heads * head_dim]   k  [num_tokens, n_kv_heads * head_dim]   (fp32, HBM)
+ * Angles come from a table computed on the host with the libm calls the reference
+ * makes (powf, cosf, sinf), so the rotation is bit-identical to it.
+ * Reference: src/kernels/layers.c:73-107. */
 void apply_rope(float* q, float* k, int pos, float theta, int head_dim, int num_tokens,
                 int n_heads, int n_kv_heads);
 
@@ -45,6 +59,7 @@ void apply_rope_batch(float* q, float* k, int* pos_arr, float theta, int head_di
                       int num_tokens, int n_heads, int n_kv_heads);
 
 /* hb = silu(h_gate) * h_up, element-wise; hb may alias h_gate.
+ *   hb, h_gate, h_up  [num_tokens, hidden_dim] fp32 in HBM;  silu(g) = g / (1 + expf(-g))
  * Reference: src/kernels/layers.c:149-161. */
 void swiglu(float* hb, float* h_gate, float* h_up, int hidden_dim, int num_tokens);
 
@@ -79,7 +94,9 @@ void update_kv_cache_paged(KVCacheManager* mgr, BlockTable* block_table, float* 
                            int layer, int pos, int n_kv_heads, int head_dim, int num_tokens);
 
 /* Scatter K/V rows of a ragged batch; token t belongs to block_tables[seq_ids[t]]
- * at position pos_arr[t].  A token whose logical block is >= table->num_blocks
+ * at position pos_arr[t]: its row lands in physical block
+ * block_indices[pos / block_size], slot pos % block_size, of layer `layer`.
+ *   k, v  [num_tokens, n_kv_heads * head_dim] fp32 in HBM  A token whose logical block is >= table->num_blocks
  * stops the call with the reference's message (attention.c:159-162).
  * Reference: src/kernels/attention.c:142-175. */
 void update_kv_cache_paged_batch(KVCacheManager* mgr, BlockTable** block_tables, int* seq_ids,
@@ -94,6 +111,12 @@ void paged_attention(float* out, float* q, KVCacheManager* mgr, BlockTable* bloc
 
 /* Causal attention of a ragged batch: token t attends to keys 0..pos_arr[t] of
  * sequence seq_ids[t].  `att` is accepted and ignored (scores never leave the CU).
+ *   out, q        [num_tokens, n_heads * head_dim] fp32 in HBM
+ *   block_tables  host array indexed by sequence id; entry s lists the physical blocks of
+ *                 sequence s in logical order (only the first pos/block_size + 1 are read)
+ *   seq_ids, pos_arr  host arrays of num_tokens ints
+ * Query head h reads kv head h / (n_heads / n_kv_heads).  The pool's element type and
+ * in-block layout are those chosen when `mgr` was initialised (nvllm_set_kv_elem_bytes).
  * Reference: src/kernels/attention.c:256-336. */
 void paged_attention_batch(float* out, float* q, KVCacheManager* mgr, BlockTable** block_tables,
                            int* seq_ids, float* att, int layer, int* pos_arr, int max_seq_len,
