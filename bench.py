@@ -246,8 +246,9 @@ def cpu_baseline(args, shape, model_path):
     bounded sample: the same batch of sequences with 2-token prompts, one prefill
     step and `cpu_steps` decode steps."""
     from nvllm_amd import capi, synth
-    kind = "reference" if os.path.exists(capi.REF_LIB) else "port"
-    lib = capi.load_ref() if kind == "reference" else capi.load_oracle()
+    from tests import checkers          # the checker is only ever the thing timed here, as the CPU baseline
+    kind = "reference" if os.path.exists(checkers.REF_LIB) else "port"
+    lib = checkers.load_ref() if kind == "reference" else checkers.load_oracle()
     B = args.batch
     prompts = synth.make_requests(B, 2, 2, shape.vocab_size, seed=11)
     devnull = os.open(os.devnull, os.O_WRONLY)

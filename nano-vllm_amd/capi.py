@@ -1,10 +1,10 @@
 """ctypes view of the C ABI declared in include/*.h.
 
-The same declarations fit three shared libraries that export the same symbols:
-the HIP library (the product), and -- for tests and the CPU baseline only -- the
-CPU oracle and the reference build under oracle/.  ``Lib`` wraps one of them.
-For the HIP library tensors live in HBM and are moved with device_memcpy; for
-the CPU libraries a "device pointer" is just a numpy buffer.
+``Lib`` wraps one shared library that exports those symbols.  The product is the
+HIP library (``load_hip``): its tensors live in HBM and are moved with
+device_memcpy.  The same declarations also fit a host-memory build of the same
+interface (kind other than 'hip': a "device pointer" is then just a numpy buffer);
+the test suite uses that to drive its CPU checkers, which live outside this package.
 """
 from __future__ import annotations
 
@@ -174,8 +174,6 @@ DEVICE_TO_HOST, DEVICE_TO_DEVICE, HOST_TO_DEVICE = 0, 1, 2
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HIP_LIB = os.path.join(PKG_DIR, "libnvllm_hip.so")
-ORACLE_LIB = os.path.join(REPO_DIR, "oracle", "liboracle.so")
-REF_LIB = os.path.join(REPO_DIR, "oracle", "_ref", "libref.so")
 
 
 def declared_symbols(hip: bool = True):
@@ -186,7 +184,8 @@ def declared_symbols(hip: bool = True):
 
 
 class Lib:
-    """One loaded library plus tensor helpers.  kind is 'hip', 'oracle' or 'ref'."""
+    """One loaded library plus tensor helpers.  kind 'hip' = tensors in HBM; any other
+    kind names a host-memory library with the same symbols."""
 
     def __init__(self, path: str, kind: str):
         if not os.path.exists(path):
@@ -247,14 +246,6 @@ def load_hip() -> Lib:
     """The product library.  Raises when it has not been built: there is no CPU
     fall-back for the forward pass."""
     return Lib(HIP_LIB, "hip")
-
-
-def load_oracle() -> Lib:
-    return Lib(ORACLE_LIB, "oracle")
-
-
-def load_ref() -> Lib:
-    return Lib(REF_LIB, "ref")
 
 
 class Engine:

@@ -14,16 +14,16 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
-    from nvllm_amd import capi
-    return capi.load_oracle()
+    from tests import checkers
+    return checkers.load_oracle()
 
 
 @pytest.fixture(scope="session")
 def ref():
-    from nvllm_amd import capi
-    if not os.path.exists(capi.REF_LIB):
+    from tests import checkers
+    if not os.path.exists(checkers.REF_LIB):
         pytest.skip("oracle/_ref/libref.so not built (needs /root/reference)")
-    return capi.load_ref()
+    return checkers.load_ref()
 
 
 @pytest.fixture(scope="session")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from nvllm_amd import capi, synth
-from tests import util
+from tests import checkers, util
 
 pytestmark = pytest.mark.gpu
 
@@ -269,7 +269,7 @@ def test_unmodified_reference_driver_runs_on_the_gpu(tmp_path):
     chunked prefill, greedy)."""
     import os
     import subprocess
-    ref_dir = os.path.dirname(capi.REF_LIB)
+    ref_dir = checkers.REF_DIR
     exe_hip, exe_ref = os.path.join(ref_dir, "nano_vllm_hip"), os.path.join(ref_dir, "nano_vllm_ref")
     if not (os.path.exists(exe_hip) and os.path.exists(exe_ref)):
         pytest.skip("oracle/_ref demo binaries not built (they need /root/reference at build time)")

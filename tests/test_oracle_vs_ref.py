@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from nvllm_amd import capi, synth
-from tests import util
+from tests import checkers, util
 
 
 def rng(seed):
@@ -124,7 +124,7 @@ def test_two_sequence_demo_matches_reference_binary(oracle, tmp_path):
     import os
     import re
     import subprocess
-    exe = os.path.join(os.path.dirname(capi.REF_LIB), "nano_vllm_ref")
+    exe = os.path.join(checkers.REF_DIR, "nano_vllm_ref")
     if not os.path.exists(exe):
         pytest.skip("reference demo binary not built")
     shape = synth.ModelShape.named("tiny", vocab_size=512, max_seq_len=64)

@@ -39,7 +39,8 @@ def main():
     wu = (r.standard_normal((F, D)) * 0.1).astype(np.float32)
     wd = (r.standard_normal((D, F)) * 0.1).astype(np.float32)
 
-    oracle = capi.load_oracle()
+    from tests import checkers
+    oracle = checkers.load_oracle()
     mm = lambda a, w: util.op_matmul(oracle, np.ascontiguousarray(a), np.ascontiguousarray(w))
     # the whole model on one rank
     full_o = mm(att, wo)

@@ -32,7 +32,8 @@ def main():
     kw = dict(n_new=spec["n_new"], arrivals=[(2 * i) % 3 for i in range(spec["n_seqs"])], collect_logits=True,
               chunk_size=spec["chunk"], temperature=0.0, max_steps=600)
 
-    oracle = capi.load_oracle()
+    from tests import checkers
+    oracle = checkers.load_oracle()
     want = util.run_engine(oracle, path, prompts, **kw)
 
     hip = capi.load_hip()
