@@ -60,6 +60,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * NBW;
     if (nb0 >= p.NB) return;   // grid padded for XCD alignment
+    NVLLM_STAMP(0, lane);
     const int kb_begin = blockIdx.y * p.kb_per_split;
     const int kb_end = min(p.Kb, kb_begin + p.kb_per_split);
     const int tb0 = blockIdx.z * TB;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         for (int j = part; j < p.e.ss_tiles; j += PARTS) ss += sp[j];
         s_part[part][tl] = ss;
     }
+    NVLLM_STAMP(1, lane);
     for (int s0 = 0; s0 < nsteps; s0 += RW) {
 #pragma unroll
         for (int r = 0; r < RW; r++) {
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
                     }
+                if (s == 0) NVLLM_STAMP(2, acc[NBW - 1][TB - 1][0]);
                 if (s + RW < nsteps) {
                     const int kbw = kb_of(s + RW);
 #pragma unroll
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             }
         }
     }
+    NVLLM_STAMP(3, acc[NBW - 1][TB - 1][0]);
     // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
     // so that they travel while the K split is being closed (every workgroup does it;
     // only the one that ends up running the epilogue uses them).  Indices are clamped,
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             v[h][q] = sum;
         }
     }
+    NVLLM_STAMP(4, v[ROUNDS - 1][IPT - 1][0]);
     // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
     const unsigned tile_id = blockIdx.z * gridDim.x + blockIdx.x;
     if (p.ksplit > 1) {
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         // ready for the next launch (nobody else touches this tile's counter any more)
         if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    NVLLM_STAMP(5, v[ROUNDS - 1][IPT - 1][0]);
     // ---- 3. epilogue on complete sums
     float ssq[ROUNDS][IPT];
 #pragma unroll
@@ -379,6 +385,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
             }
         }
     }
+#ifdef NVLLM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores issued so far have left the CU
+#endif
+    NVLLM_STAMP(6, ssq[0][0]);
 }
 
 // ------------------------------------------------------------------ launch
@@ -401,6 +411,9 @@ int gemm_pick_ksplit(int N, int K, int T) {
 
 // arrival counters: zero when allocated, every launch leaves them zero again
 static unsigned* g_counters = nullptr;
+#ifdef NVLLM_STAMPS
+unsigned long long* g_gemm_stamps = nullptr;   // set by the diagnostic harness
+#endif
 constexpr int MAX_COUNTERS = 1 << 16;
 
 template <int NBW, int TB, typename KVT>
@@ -508,6 +521,9 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     ks = cdiv(a.Kb, a.kb_per_split);
     a.ksplit = ks;
     a.counters = g_counters;
+#ifdef NVLLM_STAMPS
+    a.stamps = g_gemm_stamps;
+#endif
     a.slab = nullptr;
     if (ks > 1) {
         const size_t tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;

@@ -23,7 +23,24 @@ struct GemmArgs {
     float* slab;      // [tile][slice][round][item] float4
     unsigned* counters;
     GemmEpilogue e;
+#ifdef NVLLM_STAMPS
+    unsigned long long* stamps;   // diagnostic builds only: [workgroup][8] constant-rate clock readings
+#endif
 };
+
+// In-kernel timeline for diagnostic builds (tools/micro/proj_bench.hip): wave 0 of every workgroup
+// records the 100 MHz constant-rate clock once the value `dep` exists.  Compiled out otherwise.
+#ifdef NVLLM_STAMPS
+#define NVLLM_STAMP(k, dep)                                                                                   \
+    do {                                                                                                      \
+        unsigned long long t__;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) : "v"(dep) : "memory");            \
+        if (p.stamps && threadIdx.x == 0)                                                                     \
+            p.stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = t__; \
+    } while (0)
+#else
+#define NVLLM_STAMP(k, dep) do {} while (0)
+#endif
 
 __device__ __forceinline__ float silu_mul(float g, float u) {
     // reference layers.c:156-158: g / (1 + expf(-g)) * u
