@@ -52,6 +52,22 @@ const int* nvllm_last_argmax(int* num_outputs);
 void nvllm_set_kv_elem_bytes(int bytes);
 int  nvllm_get_kv_elem_bytes(void);
 
+/* ------------------------------------------------ matmul without allocation */
+/* No counterpart in the reference.  For callers that cannot allocate device memory:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * Same result as matmul() (ops.h; reference src/kernels/layers.c:44-67) for a `weight`
+ * handle that load_model produced and at most 64 tokens with in_dim <= 8192: the re-packed
+ * activations, the split-K partial tiles and the arrival counters live in a static
+ * device array of the library (6.1 MiB per GPU, held until the process ends) instead of
+ * buffers the library allocates on demand.  Calls no hipMalloc / hipFree.  The library
+ * must already be initialised (init_ops()).  Enqueues on nvllm_stream() and returns
+ * without synchronising, like matmul().  All calls on one GPU share the one array:
+ * calls that overlap on a GPU race.
+ * Returns 0; -1 library not initialised; -2 `weight` is not a projection handle of this
+ * shape; -3 sizes beyond the limits (message on stderr, nothing enqueued). */
+int nvllm_matmul_noalloc(float* out, const float* in, const float* weight, int num_tokens,
+                         int in_dim, int out_dim);
+
 /* ---------------------------------------------------------- kernel timing */
 /* With timing on, every kernel is launched with a start and a stop event attached to
  * its dispatch (hipExtLaunchKernelGGL), so the elapsed time is the kernel's own

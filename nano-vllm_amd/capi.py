@@ -160,6 +160,7 @@ _HIP_ONLY = {
     "nvllm_prof_get": (_V, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nvllm_free_model": (_V, [C.POINTER(Weights)]),
+    "nvllm_matmul_noalloc": (_I, [_P, _P, _P, _I, _I, _I]),
     "nvllm_tp_shard": (_I, [C.POINTER(Config), _I, _I, C.POINTER(TpShard)]),
     "nvllm_tp_unique_id": (_I, [_P]),
     "nvllm_tp_init": (_I, [_I, _I, _P]),

@@ -436,13 +436,15 @@ static void launch_tb(const GemmArgs& a, dim3 grid) {
 }
 
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
-                const GemmEpilogue& epi, int force_ksplit, int prof_cls) {
+                const GemmEpilogue& epi, int force_ksplit, int prof_cls, const GemmWorkspace* wsp) {
     if (T <= 0 || N <= 0) return 1;
     ensure_init();
-    if (!g_counters) {
+    // the caller's workspace (counters already zero), or the library's own grow-only buffers
+    if (!wsp && !g_counters) {
         HIP_CHECK(hipMalloc((void**)&g_counters, MAX_COUNTERS * sizeof(unsigned)));
         HIP_CHECK(hipMemsetAsync(g_counters, 0, MAX_COUNTERS * sizeof(unsigned), rt().stream));
     }
+    const long max_counters = wsp ? wsp->n_counters : MAX_COUNTERS;
     GemmArgs a;
     a.W = tiles;
     a.nb_stride = w.nb_stride;
@@ -467,7 +469,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     // Hundreds of tokens (prefill chunks): the contraction is dense enough for the
     // LDS-shared 128 x 128 tiles of gemm_prefill.hip.
     static const int pf_min_t = getenv("NVLLM_GEMM_PREFILL_T") ? atoi(getenv("NVLLM_GEMM_PREFILL_T")) : 256;
-    if (force_ksplit <= 0 && T >= pf_min_t) {
+    if (force_ksplit <= 0 && T >= pf_min_t && !wsp) {
         ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
         launch_gemm_prefill(a);
         return 1;
@@ -516,18 +518,24 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     // the 8 XCDs, a grid width that is a multiple of 8 puts them behind the same L2 (speed
     // only; surplus workgroups exit at once).
     if (tiles_t > 1 && ks == 1) tiles_n = (tiles_n + 7) & ~7;
-    if ((long)tiles_n * tiles_t > MAX_COUNTERS) ks = 1;
+    if ((long)tiles_n * tiles_t > max_counters) ks = 1;
     a.kb_per_split = cdiv(a.Kb, ks);
     ks = cdiv(a.Kb, a.kb_per_split);
+    const size_t slab_tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
+    // a caller's slab that cannot hold the partial tiles: every workgroup sweeps the whole K instead
+    if (wsp && ks > 1 && (size_t)tiles_n * tiles_t * ks * slab_tile_bytes > wsp->slab_bytes) {
+        ks = 1;
+        a.kb_per_split = a.Kb;
+    }
     a.ksplit = ks;
-    a.counters = g_counters;
+    a.counters = wsp ? wsp->counters : g_counters;
 #ifdef NVLLM_STAMPS
     a.stamps = g_gemm_stamps;
 #endif
     a.slab = nullptr;
     if (ks > 1) {
-        const size_t tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
-        a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles_n * tiles_t * ks * tile_bytes);
+        const size_t need = (size_t)tiles_n * tiles_t * ks * slab_tile_bytes;
+        a.slab = wsp ? wsp->slab : (float*)ws_get(WS_SLAB, need);
     }
     const dim3 grid(tiles_n, ks, tiles_t);
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);

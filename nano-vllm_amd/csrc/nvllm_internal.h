@@ -84,6 +84,9 @@ struct Runtime {
 };
 Runtime& rt();
 void ensure_init();
+// noalloc.hip: resolves the device address of the library's static scratch array for the current
+// device (called once by ensure_init, after hipSetDevice)
+void noalloc_setup(int device);
 
 // Tensor parallelism (tp.hip).  `active` selects the forward pass that leaves the two
 // residual projections as partial sums and all-reduces them.
@@ -150,6 +153,12 @@ hipEvent_t prof_stop_event();
 #define NVLLM_LAUNCH(kernel, grid, block, shmem, ...)                                                   \
     hipExtLaunchKernelGGL(kernel, grid, block, shmem, ::nvllm::rt().stream, ::nvllm::prof_start_event(), \
                           ::nvllm::prof_stop_event(), 0, __VA_ARGS__)
+// While one exists, ProfScope records nothing (and so creates no events): for entry points that
+// must not allocate.
+struct ProfSuppress {
+    ProfSuppress();
+    ~ProfSuppress();
+};
 struct ProfScope {  // names the class of, and attaches timing events to, the ONE launch made inside it
     ProfScope(int cls, double bytes, double flops);
     ~ProfScope();
@@ -191,9 +200,19 @@ struct GemmEpilogue {
     int bs = 16;
     long layer_off = 0;
 };
-// out = A16[T, K] x W[N, K]^T followed by the epilogue.  Returns the K-split used.
+// Memory a projection launch needs beyond its operands, when the caller brings it instead of the
+// library's grow-only buffers: a slab for split-K partial tiles and zeroed arrival counters (every
+// launch leaves them zero again).  A slab too small for the chosen K split means no K split.
+struct GemmWorkspace {
+    float* slab;
+    size_t slab_bytes;
+    unsigned* counters;
+    int n_counters;
+};
+// out = A16[T, K] x W[N, K]^T followed by the epilogue.  Returns the K-split used.  With `wsp` the
+// launch allocates nothing (decode-sized batches only: the dense prefill kernel is not taken).
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
-                const GemmEpilogue& epi, int force_ksplit, int prof_cls);
+                const GemmEpilogue& epi, int force_ksplit, int prof_cls, const GemmWorkspace* wsp = nullptr);
 int gemm_pick_ksplit(int N, int K, int T);
 int gemm_feature_tiles(int N);   // 32-feature groups of a projection output = columns of ss_out
 void gemm_release();

@@ -144,8 +144,12 @@ static hipEvent_t g_cur_start = nullptr, g_cur_stop = nullptr;
 hipEvent_t prof_start_event() { return g_cur_start; }
 hipEvent_t prof_stop_event() { return g_cur_stop; }
 
+static int g_prof_suppress = 0;
+ProfSuppress::ProfSuppress() { g_prof_suppress++; }
+ProfSuppress::~ProfSuppress() { g_prof_suppress--; }
+
 ProfScope::ProfScope(int cls, double bytes, double flops) : slot(-1) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || g_prof_suppress > 0) return;
     ProfRec r{cls, prof_event(), prof_event(), bytes, flops};
     slot = (int)g_prof_pending.size();
     g_prof_pending.push_back(r);
@@ -192,6 +196,7 @@ void ensure_init() {
     }
     const char* kv = getenv("NVLLM_KV_BYTES");
     if (kv && (atoi(kv) == 2 || atoi(kv) == 4)) g_rt.kv_elem_bytes = atoi(kv);
+    noalloc_setup(g_rt.device);
     g_rt.inited = true;
 }
 

@@ -1,0 +1,58 @@
+"""nvllm_matmul_noalloc (include/nvllm.h): matmul() for callers that cannot allocate.
+Checked against matmul() itself through the C ABI -- same kernels, same K split, so the
+results must be bit-identical -- on two calls in a row, the second with a smaller input
+(the static scratch array keeps the first call's contents)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from nvllm_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(hip, handle, x, K, N):
+    T = x.shape[0]
+    dx = hip.to_device(x)
+    d_ref, d_new = hip.empty_device(T * N * 4), hip.to_device(np.full((T, N), np.nan, np.float32))
+    hip.matmul(d_ref, dx, handle, T, K, N)
+    rc = hip.nvllm_matmul_noalloc(d_new, dx, handle, T, K, N)
+    assert rc == 0
+    want, got = hip.to_host(d_ref, (T, N)), hip.to_host(d_new, (T, N))
+    for p in (dx, d_ref, d_new):
+        hip.free(p)
+    return want, got
+
+
+def test_matmul_noalloc_matches_matmul_twice_in_a_row(hip, tmp_models):
+    # hidden_dim 4096: w_down runs with a K split (partial tiles through the slab + arrival counters)
+    path, shape = tmp_models("tiny", seed=71, dim=256, hidden_dim=4096, n_layers=1, n_heads=4, n_kv_heads=2,
+                             vocab_size=777, max_seq_len=128)
+    w, cfg = capi.Weights(), capi.Config()
+    hip.load_model(C.byref(w), C.byref(cfg), path.encode())
+    try:
+        D, F, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+        lw = w.layers[0]
+        r = np.random.Generator(np.random.PCG64(72))
+        # first call: the widest batch; second call: fewer tokens AND a shorter K, right after it
+        for handle, K, N, tokens in ((lw.w_down, F, D, (64, 5)), (lw.w_gate, D, F, (33, 1)), (w.lm_head, D, V, (64, 17))):
+            for T in tokens:
+                x = r.standard_normal((T, K)).astype(np.float32)
+                want, got = _both(hip, handle, x, K, N)
+                assert np.isfinite(got).all()
+                np.testing.assert_array_equal(got, want)
+        x_big = r.standard_normal((64, F)).astype(np.float32)
+        x_small = r.standard_normal((3, D)).astype(np.float32)
+        for handle, x, K, N in ((lw.w_down, x_big, F, D), (lw.wq, x_small, D, D)):
+            want, got = _both(hip, handle, x, K, N)
+            np.testing.assert_array_equal(got, want)
+        # limits and bad handles are refused with an error code, nothing is enqueued
+        dx, do = hip.to_device(np.zeros((65, D), np.float32)), hip.empty_device(65 * D * 4)
+        assert hip.nvllm_matmul_noalloc(do, dx, lw.wq, 65, D, D) == -3
+        assert hip.nvllm_matmul_noalloc(do, dx, lw.wq, 4, D, D + 16) == -2
+        assert hip.nvllm_matmul_noalloc(do, dx, dx, 4, D, D) == -2
+        hip.free(dx)
+        hip.free(do)
+    finally:
+        hip.nvllm_free_model(C.byref(w))
