@@ -14,8 +14,11 @@ extern "C" {
 /* Read a model file in the reference's format (7-int header, tensors grouped by
  * parameter type across layers, fp16 or fp32, shared or separate classifier,
  * detected from the file size) and place it in HBM.  Matrices are kept as fp16
- * in MFMA tile order (fp32 files are rounded to fp16 only if every value is
- * exactly representable; otherwise loading aborts), norm vectors as fp32.
+ * in MFMA tile order, norm vectors as fp32.  An fp32 file takes that form only if
+ * every matrix value is exactly representable in fp16 (nothing is rounded);
+ * otherwise its tensors stay fp32 in HBM, one row-major buffer per tensor as in the
+ * reference, and the forward pass runs on the fp32 operators -- exact weights,
+ * slower.  Prints the reference's report of the header and the detected format.
  * Fills p (incl. head_dim, rope_theta) and w.  Fatal errors print to stderr and
  * exit(1) like the reference.  Reference: src/model.c:110-285. */
 void load_model(Weights* w, Config* p, const char* checkpoint_path);

@@ -40,6 +40,15 @@ int  nvllm_get_logits_mode(void);
  * num_outputs entries, valid until the next call). */
 const int* nvllm_last_argmax(int* num_outputs);
 
+/* The device arg-max of the forward pass on caller-supplied rows: out[r] (host) = first
+ * index of the maximum of logits[r*vocab_size ..] (device memory), the reference's rule
+ * (strict '>' scan from index 0, src/sampler.c:86-97: ties go to the lowest index, a row
+ * of -inf answers 0).  slices > 1 takes the path of a tensor-parallel classifier instead:
+ * the vocabulary is cut into `slices` runs of whole 16-row blocks as nvllm_tp_shard cuts
+ * it over ranks, every slice reports one (maximum, index) pair per row and the pairs are
+ * merged.  Synchronous.  Returns 0, or -1 on bad arguments. */
+int nvllm_argmax_rows(int* out, const float* logits, int num_rows, int vocab_size, int slices);
+
 /* Element type of the KV pool that init_kv_cache_manager allocates next:
  * 4 = fp32 (the reference's row layout, src/memory.c:37-43, bit-exact copies);
  * 2 = fp16 (half the bytes; values rounded to nearest-even and saturated to the

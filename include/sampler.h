@@ -28,17 +28,21 @@ typedef struct {
 void build_sampler(Sampler* s, int vocab_size, float temperature, float topp,
                    unsigned long long seed);
 
-/* Next token for one row of logits.  temperature == 0: first index of the
- * maximum (strict '>' scan, reference src/sampler.c:86-97).  In the HIP library
- * a row that belongs to the most recent transformer_batch call is answered from
- * the arg-max computed on the GPU during that call; any other row is reduced by
- * the same kernel after an upload.  temperature > 0 (reference
- * src/sampler.c:100-139): the GPU turns the rows of the most recent pass into
- * softmax(logits / temperature) and compacts the nucleus candidates
- * (prob >= (1 - topp) / (n - 1), in index order); the host sorts them with the
- * reference's comparator and draws with the reference's coin, libc rand()
- * seeded by build_sampler.  The row is NOT rewritten in place (the reference
- * leaves the probabilities in it; its driver never reads them). */
+/* Next token for one row of logits (reference src/sampler.c:84-140).
+ * temperature == 0: first index of the maximum (strict '>' scan, sampler.c:86-97).
+ * temperature > 0 (sampler.c:100-139): softmax(logits / temperature), then plain or
+ * nucleus sampling -- candidates with prob >= (1 - topp) / (n - 1), sorted with the
+ * reference's comparator, drawn with the reference's coin, libc rand() seeded by
+ * build_sampler.  In the HIP library the softmax and the candidate filter run on the GPU.
+ * Which memory is read depends on the hand-off mode (nvllm.h, nvllm_set_logits_mode):
+ *   NVLLM_LOGITS_HOST    `logits` is host memory and is read as the caller left it, so
+ *                        edits made after transformer_batch (logit bias, banned tokens)
+ *                        count; with a temperature the row is rewritten in place to the
+ *                        probabilities, as the reference does (sampler.c:100-121).
+ *   NVLLM_LOGITS_ARGMAX  RunState.logits is never filled: a pointer to its row k names
+ *                        output k of the most recent transformer_batch call, which is
+ *                        answered from the logits still in HBM (host edits cannot exist).
+ *                        Any other pointer is treated as a host row, as above. */
 int sample(Sampler* s, float* logits);
 
 #ifdef __cplusplus

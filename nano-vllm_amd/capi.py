@@ -151,6 +151,7 @@ _HIP_ONLY = {
     "nvllm_set_logits_mode": (_V, [_I]),
     "nvllm_get_logits_mode": (_I, []),
     "nvllm_last_argmax": (c_int_p, [c_int_p]),
+    "nvllm_argmax_rows": (_I, [c_int_p, _P, _I, _I, _I]),
     "nvllm_set_kv_elem_bytes": (_V, [_I]),
     "nvllm_get_kv_elem_bytes": (_I, []),
     "nvllm_prof_enable": (_V, [_I]),

@@ -178,6 +178,22 @@ void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const floa
                        ss_tiles);
 }
 
+// Rows idx[r] of an fp32 [*, D] table -> rows r of dst (the embedding lookup and the output
+// gather of the forward pass on fp32 weights: reference model.c:352-355, 411-414).
+__global__ __launch_bounds__(256) void k_gather_rows_f32(float* __restrict__ dst, const float* __restrict__ src,
+                                                         const int* __restrict__ idx, int D) {
+    const float4* s = reinterpret_cast<const float4*>(src + (size_t)idx[blockIdx.x] * D);
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)blockIdx.x * D);
+    for (int i = threadIdx.x; i < D / 4; i += blockDim.x) d[i] = s[i];
+}
+
+void launch_gather_rows_f32(float* dst, const float* src, const int* idx, int B, int D) {
+    if (B <= 0) return;
+    if (D % 4) NVLLM_FATAL("row width %d is not a multiple of 4", D);
+    ProfScope ps(PC_EMBED, (double)B * D * 8.0, 0);
+    NVLLM_LAUNCH(k_gather_rows_f32, dim3(B), dim3(256), 0, dst, src, idx, D);
+}
+
 // ------------------------------------------------------------------ RMSNorm
 // ops.h rms_norm (reference layers.c:23-38).  One workgroup per row; arithmetic per
 // element as layers.c:32-35: r = 1/sqrtf(ss/D + eps), out = (x * r) * g.  (Inside the

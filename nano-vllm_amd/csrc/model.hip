@@ -37,7 +37,51 @@ struct ModelPriv {
     const float* rms_final = nullptr;
     std::vector<LayerPriv> layers;
     std::vector<const void*> handles;
+    // An fp32 file with values that fp16 cannot hold stays fp32: one row-major HBM buffer per
+    // tensor (the public Weights pointers are those buffers, as in the reference) and the
+    // forward pass runs the fp32 operators one by one.
+    bool f32 = false;
+    std::vector<void*> f32_bufs;
 };
+
+// Does fp16 hold this fp32 value exactly?  (Zero, or a normal/subnormal fp16 value; no NaN.)
+static inline bool fp16_exact(uint32_t bits) {
+    const uint32_t e = (bits >> 23) & 0xffu, man = bits & 0x7fffffu;
+    if (e == 0) return man == 0;            // zero; fp32 subnormals are far below fp16's range
+    if (e == 255) return man == 0;          // infinity
+    const int E = (int)e - 127;
+    if (E > 15) return false;
+    if (E >= -14) return (man & 0x1fffu) == 0;
+    if (E < -24) return false;
+    const uint32_t full = man | 0x800000u;  // 1.m as a 24-bit integer: value = full * 2^(E-23), grid 2^-24
+    return (full & ((1u << (-(E + 1))) - 1u)) == 0;
+}
+
+// Scan the matrices of an fp32 model file (everything but the norm vectors, which stay fp32
+// anyway): true when every value survives a round trip through fp16.
+static bool f32_file_fits_fp16(FILE* f, long start, const std::vector<std::pair<long long, bool>>& tensors) {
+    const size_t CH = 1 << 20;
+    std::vector<uint32_t> buf(CH);
+    bool ok = true;
+    fseek(f, start, SEEK_SET);
+    for (const auto& t : tensors) {
+        long long left = t.first;
+        if (!t.second) {   // a norm vector: skip
+            fseek(f, (long)(left * 4), SEEK_CUR);
+            continue;
+        }
+        while (left > 0 && ok) {
+            const size_t n = (size_t)std::min<long long>(left, (long long)CH);
+            if (fread(buf.data(), 4, n, f) != n) { ok = false; break; }
+            for (size_t i = 0; i < n; i++)
+                if (!fp16_exact(buf[i])) { ok = false; break; }
+            left -= (long long)n;
+        }
+        if (!ok) break;
+    }
+    fseek(f, start, SEEK_SET);
+    return ok;
+}
 
 // State of the most recent forward pass, for sample() and nvllm_last_argmax().
 static int* g_argmax_host = nullptr;   // pinned
@@ -68,6 +112,126 @@ static void tp_gather_logits(float* full, const float* local, int rows, int slic
     launch_logits_unshard(full, parts, W, rows, slice, V);
 }
 
+// End of a forward pass: results to the host, and what sample() needs to recognise its rows.
+static void finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V) {
+    if (B > g_argmax_cap) {
+        if (g_argmax_host) HIP_CHECK(hipHostFree(g_argmax_host));
+        g_argmax_cap = B + 256;
+        HIP_CHECK(hipHostMalloc((void**)&g_argmax_host, (size_t)g_argmax_cap * sizeof(int), hipHostMallocDefault));
+    }
+    hipStream_t stream = rt().stream;
+    HIP_CHECK(hipMemcpyAsync(g_argmax_host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (rt().logits_mode == NVLLM_LOGITS_HOST)
+        HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));  // the call is synchronous, like the CPU reference
+    g_last_outputs = B;
+    g_pass_serial++;
+    g_last_logits_host = s->logits;
+    g_last_logits_dev = d_logits;
+    g_last_vocab = V;
+}
+
+// ---- fp32 files whose values fp16 cannot hold (e.g. a trained llama2.c stories15M.bin) ----
+// Loaded as the reference does (model.c:87-108, 230-279): one fp32 row-major buffer per
+// tensor, in file order; the classifier aliases the embedding when the file shares them.
+static void load_model_f32(Weights* w, Config* p, FILE* f, bool shared) {
+    if (tp().world > 1) {
+        fprintf(stderr, "fp32 model files with values outside fp16 are not split over tensor-parallel ranks; convert the file to fp16\n");
+        exit(1);
+    }
+    const size_t D = p->dim, F = p->hidden_dim, V = p->vocab_size;
+    const size_t QD = (size_t)p->n_heads * p->head_dim, KD = (size_t)p->n_kv_heads * p->head_dim;
+    const int L = p->n_layers;
+    ModelPriv* m = new ModelPriv();
+    m->cfg = *p;
+    nvllm_tp_shard(p, 0, 1, &m->sh);
+    m->f32 = true;
+    const size_t biggest = std::max(std::max(V * D, D * F), D * QD);
+    float* host = (float*)malloc(biggest * sizeof(float));
+    if (!host) NVLLM_FATAL("no memory for the %zu-byte load buffer", biggest * sizeof(float));
+    float dbg0 = 0.f, dbg100 = 0.f;
+    bool first = true;
+    auto load = [&](size_t n, const char* what) -> float* {   // model.c:87-108
+        read_exact(f, host, n * sizeof(float), what);
+        if (first) {
+            dbg0 = host[0];
+            dbg100 = host[std::min<size_t>(100, n - 1)];
+            first = false;
+        }
+        void* d = nullptr;
+        if (device_malloc(&d, n * sizeof(float)) != 0) NVLLM_FATAL("cannot allocate %zu bytes of HBM for %s", n * sizeof(float), what);
+        device_memcpy(d, host, n * sizeof(float), HOST_TO_DEVICE);   // synchronous: `host` is reused
+        m->f32_bufs.push_back(d);
+        return (float*)d;
+    };
+    w->layers = (LayerWeights*)malloc((size_t)L * sizeof(LayerWeights));
+    w->token_embedding_table = load(V * D, "token_embedding_table");
+    for (int l = 0; l < L; l++) w->layers[l].rms_att_weight = load(D, "rms_att_weight");
+    for (int l = 0; l < L; l++) w->layers[l].wq = load(D * QD, "wq");
+    for (int l = 0; l < L; l++) w->layers[l].wk = load(D * KD, "wk");
+    for (int l = 0; l < L; l++) w->layers[l].wv = load(D * KD, "wv");
+    for (int l = 0; l < L; l++) w->layers[l].wo = load(QD * D, "wo");
+    for (int l = 0; l < L; l++) w->layers[l].rms_ffn_weight = load(D, "rms_ffn_weight");
+    for (int l = 0; l < L; l++) w->layers[l].w_gate = load(D * F, "w_gate");
+    for (int l = 0; l < L; l++) w->layers[l].w_down = load(F * D, "w_down");   // file order: down before up (model.c:262-269)
+    for (int l = 0; l < L; l++) w->layers[l].w_up = load(D * F, "w_up");
+    w->rms_final_weight = load(D, "rms_final_weight");
+    if (shared) {
+        w->lm_head = w->token_embedding_table;
+        printf("Weights shared: lm_head -> token_embedding_table\n");
+    } else {
+        w->lm_head = load(V * D, "lm_head");
+    }
+    fclose(f);
+    free(host);
+    w->_data_buffer = m;
+    printf("Model loaded.\n");
+    printf("DEBUG: Embed[0]: %f\n", dbg0);
+    printf("DEBUG: Embed[100]: %f\n", dbg100);
+}
+
+// The reference's layer loop (model.c:352-418) on fp32 weights, one operator launch per
+// reference call; leaves the logits of the output rows in d_logits.
+static void forward_f32(const StepArrays& st, int T, int B, Config* p, RunState* s, Weights* w, const KvPoolView& pool,
+                        const float2* rope, float* d_logits) {
+    const int D = p->dim, F = p->hidden_dim, hd = p->head_dim, H = p->n_heads, KVH = p->n_kv_heads;
+    const int QD = H * hd, KD = KVH * hd, V = p->vocab_size;
+    const float eps = 1e-5f;
+    launch_gather_rows_f32(s->x, w->token_embedding_table, st.d_tokens, T, D);
+    for (int l = 0; l < p->n_layers; l++) {
+        const LayerWeights& lw = w->layers[l];
+        launch_rmsnorm_f32(s->xb, s->x, lw.rms_att_weight, D, T, eps);
+        launch_matmul_f32w(s->q, s->xb, lw.wq, T, D, QD);
+        launch_matmul_f32w(s->k, s->xb, lw.wk, T, D, KD);
+        launch_matmul_f32w(s->v, s->xb, lw.wv, T, D, KD);
+        launch_rope(s->q, s->k, st.d_pos, 0, rope, T, H, KVH, hd);
+        launch_kv_write(s->k, s->v, st.d_pos, 0, st.d_seq, st.d_tbl_off, st.d_tables, pool, l, st.write_limit, KVH, hd);
+        AttnArgs at{};
+        at.q = s->q;
+        at.out_f32 = s->xb2;
+        at.pool = pool;
+        at.layer = l;
+        at.tables = st.d_tables;
+        at.T = T; at.H = H; at.KVH = KVH; at.hd = hd;
+        at.max_pos = st.max_pos;
+        at.runs = st.d_runs;
+        at.n_runs = st.n_runs;
+        at.kv_positions = st.kv_positions;
+        launch_paged_attention(at);
+        launch_matmul_f32w(s->xb, s->xb2, lw.wo, T, QD, D);
+        launch_accum(s->x, s->xb, (long)T * D);
+        launch_rmsnorm_f32(s->xb, s->x, lw.rms_ffn_weight, D, T, eps);
+        launch_matmul_f32w(s->hb, s->xb, lw.w_gate, T, D, F);
+        launch_matmul_f32w(s->hb2, s->xb, lw.w_up, T, D, F);
+        launch_swiglu(s->hb, s->hb, s->hb2, (long)T * F);
+        launch_matmul_f32w(s->xb, s->hb, lw.w_down, T, F, D);
+        launch_accum(s->x, s->xb, (long)T * D);
+    }
+    launch_rmsnorm_f32(s->x, s->x, w->rms_final_weight, D, T, eps);
+    launch_gather_rows_f32(s->xb, s->x, st.d_out_idx, B, D);
+    launch_matmul_f32w(d_logits, s->xb, w->lm_head, B, D, V);
+}
+
 }  // namespace nvllm
 
 using namespace nvllm;
@@ -96,17 +260,41 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     p->head_dim = p->dim / p->n_heads;  // model.c:144
     p->rope_theta = 10000.0f;           // model.c:146
 
+    // the reference's report of what it found (model.c:148-157)
+    printf("Model Config:\n");
+    printf("  dim: %d\n", p->dim);
+    printf("  n_layers: %d\n", p->n_layers);
+    printf("  n_heads: %d\n", p->n_heads);
+    printf("  n_kv_heads: %d\n", p->n_kv_heads);
+    printf("  vocab_size: %d\n", p->vocab_size);
+    printf("  max_seq_len: %d\n", p->max_seq_len);
+    printf("  hidden_dim: %d\n", p->hidden_dim);
+    printf("  head_dim: %d\n", p->head_dim);
+    printf("  rope_theta: %f\n", p->rope_theta);
+
     const long long D = p->dim, F = p->hidden_dim, L = p->n_layers, V = p->vocab_size;
     const long long QD = (long long)p->n_heads * p->head_dim, KD = (long long)p->n_kv_heads * p->head_dim;
     const long long body = V * D + L * (2 * D + D * QD + 2 * D * KD + QD * D + 3 * D * F) + D;
     const long long headw = V * D;
     const long long rope_tail = (long long)p->max_seq_len * p->head_dim * 4;
-    int fp32, shared;  // size-based detection, model.c:187-220
-    if (payload == body * 4 || payload == body * 4 + rope_tail) { fp32 = 1; shared = 1; }
-    else if (payload == (body + headw) * 4)                     { fp32 = 1; shared = 0; }
-    else if (payload == (body + headw) * 2)                     { fp32 = 0; shared = 0; }
-    else if (payload == body * 2)                               { fp32 = 0; shared = 1; }
-    else {
+    printf("File data size: %ld bytes\n", (long)payload);                       // model.c:194-197
+    printf("Expected FP32 Shared (Raw): %lld\n", body * 4);
+    printf("Expected FP32 Shared (+RoPE): %lld\n", body * 4 + rope_tail);
+    printf("Expected FP16 Unshared: %lld\n", (body + headw) * 2);
+    int fp32, shared;  // size-based detection, model.c:199-220
+    if (payload == body * 4 || payload == body * 4 + rope_tail) {
+        fp32 = 1; shared = 1;
+        printf("Detected format: FP32 Shared Weights (Legacy%s)\n", payload == body * 4 + rope_tail ? " + RoPE" : "");
+    } else if (payload == (body + headw) * 4) {
+        fp32 = 1; shared = 0;
+        printf("Detected format: FP32 Unshared Weights\n");
+    } else if (payload == (body + headw) * 2) {
+        fp32 = 0; shared = 0;
+        printf("Detected format: FP16 Unshared Weights (Nano Export)\n");
+    } else if (payload == body * 2) {
+        fp32 = 0; shared = 1;
+        printf("Detected format: FP16 Shared Weights\n");
+    } else {
         printf("Warning: File size matches none of the expected formats! Trying FP16 Unshared as fallback...\n");
         fp32 = 0; shared = 0;
     }
@@ -115,7 +303,25 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
                 D, F, QD, KD, p->head_dim);
         exit(1);
     }
-    if (fp32) printf("nvllm: fp32 checkpoint: matrices are rounded to fp16 for HBM residency\n");
+    printf("Loading weights...\n");                                             // model.c:226
+    // An fp32 file goes to the fp16 tile layout only if that loses nothing; otherwise it
+    // stays fp32 in HBM and the forward pass runs on the fp32 operators (load_model_f32).
+    if (fp32) {
+        std::vector<std::pair<long long, bool>> tensors;   // (elements, is a matrix) in file order
+        tensors.push_back({V * D, true});
+        tensors.push_back({L * D, false});
+        tensors.push_back({L * D * QD, true});
+        tensors.push_back({2 * L * D * KD, true});
+        tensors.push_back({L * QD * D, true});
+        tensors.push_back({L * D, false});
+        tensors.push_back({3 * L * D * F, true});
+        tensors.push_back({D, false});
+        if (!shared) tensors.push_back({V * D, true});
+        if (!f32_file_fits_fp16(f, header, tensors)) {
+            load_model_f32(w, p, f, shared != 0);
+            return;
+        }
+    }
     // tensor parallelism: this process keeps the heads / hidden columns of its rank
     NvllmTpShard sh;
     if (nvllm_tp_shard(p, tp().rank, tp().world, &sh) != 0) {
@@ -211,6 +417,9 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     const long str_D = (long)Kb_D * TILE_HALVES, str_QD = (long)Kb_QD * TILE_HALVES, str_F = (long)Kb_F * TILE_HALVES;
 
     fetch(V * D, "token_embedding_table");
+    // the two values the reference prints through its "device" pointer (model.c:283-284); `host` still holds the table
+    auto host_elem = [&](size_t i) { return fp32 ? ((const float*)host)[i] : __half2float(((const __half*)host)[i]); };
+    const float dbg0 = host_elem(0), dbg100 = host_elem((size_t)std::min<long long>(100, V * D - 1));
     HIP_CHECK(hipMemcpyAsync((void*)m->embed, stage16, V * D * 2, hipMemcpyDeviceToDevice, st));
     if (shared) tile_into(m->head, Vh, D, str_D, v0);
     HIP_CHECK(hipStreamSynchronize(st));
@@ -224,8 +433,12 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     for (int l = 0; l < L; l++) { fetch_cols(D, F, f0, Fl, "w_down"); tile_into(m->layers[l].down, D, Fl, str_F); }  // file order: down before up (model.c:262-269)
     for (int l = 0; l < L; l++) { fetch_rows(F, D, f0, Fl, "w_up"); tile_into(m->layers[l].gateup + str_D, Fl, D, 2 * str_D); }
     fetch_vec(m->rms_final, D, "rms_final_weight");
-    if (!shared) { fetch_rows(V, D, v0, Vh, "lm_head"); tile_into(m->head, Vh, D, str_D); }
+    if (shared) printf("Weights shared: lm_head -> token_embedding_table\n");   // model.c:273-276
+    else { fetch_rows(V, D, v0, Vh, "lm_head"); tile_into(m->head, Vh, D, str_D); }
     fclose(f);
+    printf("Model loaded.\n");
+    printf("DEBUG: Embed[0]: %f\n", dbg0);
+    printf("DEBUG: Embed[100]: %f\n", dbg100);
     free(host);
     device_free(stage);
     if (fp32) device_free(stage16);
@@ -266,7 +479,8 @@ void nvllm_free_model(Weights* w) {
     if (!w || !w->_data_buffer) return;
     ModelPriv* m = (ModelPriv*)w->_data_buffer;
     for (const void* h : m->handles) unregister_weight(h);
-    device_free(m->arena);
+    if (m->arena) device_free(m->arena);
+    for (void* q : m->f32_bufs) device_free(q);
     delete m;
     free(w->layers);
     memset(w, 0, sizeof *w);
@@ -274,7 +488,8 @@ void nvllm_free_model(Weights* w) {
 
 // ------------------------------------------------------------- workspace
 // Reference src/model.c:287-336.  Same buffers, same capacities; `logits` is
-// page-locked host memory (the driver reads it, the sampler rewrites it).
+// page-locked host memory (the driver reads it; sample() with a temperature rewrites
+// the row it is given to probabilities, as the reference's does).
 void malloc_run_state(RunState* s, Config* p) {
     ensure_init();
     const size_t S = (size_t)p->max_seq_len, D = p->dim, F = p->hidden_dim;
@@ -353,6 +568,14 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     float* ss_b = ss + (size_t)T * ssn;     // ... entering an MLP block
     float* d_logits = (float*)ws_get(WS_LOGITS, (size_t)B * V * sizeof(float));
     int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
+
+    if (m->f32) {   // fp32 weights: the reference's operator sequence
+        forward_f32(st, T, B, p, s, w, pool, rope, d_logits);
+        launch_argmax(d_argmax, d_logits, B, V);
+        g_tp_full_valid = true;
+        finish_pass(s, d_logits, d_argmax, B, V);
+        return;
+    }
 
     // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
     launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D);
@@ -471,21 +694,31 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         }
     }
 
-    if (B > g_argmax_cap) {
-        if (g_argmax_host) HIP_CHECK(hipHostFree(g_argmax_host));
-        g_argmax_cap = B + 256;
-        HIP_CHECK(hipHostMalloc((void**)&g_argmax_host, (size_t)g_argmax_cap * sizeof(int), hipHostMallocDefault));
+    finish_pass(s, d_logits, d_argmax, B, V);
+}
+
+// The arg-max kernels of the forward pass on caller-supplied rows (include/nvllm.h).
+int nvllm_argmax_rows(int* out, const float* logits, int num_rows, int vocab_size, int slices) {
+    ensure_init();
+    if (num_rows <= 0 || vocab_size <= 0 || !out || !logits) return -1;
+    const int B = num_rows, V = vocab_size;
+    int* d_out = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
+    if (slices <= 1) {
+        launch_argmax(d_out, logits, B, V);
+    } else {
+        // slices of whole 16-row blocks, as nvllm_tp_shard cuts the classifier over ranks
+        const int per = ((V + 15) / 16 + slices - 1) / slices * 16;
+        float2* pairs = (float2*)ws_get(WS_TP_GATHER, (size_t)slices * B * sizeof(float2));
+        for (int r = 0; r < slices; r++) {
+            const int v0 = (long)r * per < V ? r * per : V;
+            const int n = V - v0 < per ? V - v0 : per;   // may be 0: that slice reports (-inf, v0)
+            launch_argmax_pairs(pairs + (size_t)r * B, logits + v0, B, n, V, v0);
+        }
+        launch_argmax_merge(d_out, pairs, slices, B);
     }
-    hipStream_t stream = rt().stream;
-    HIP_CHECK(hipMemcpyAsync(g_argmax_host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (rt().logits_mode == NVLLM_LOGITS_HOST)
-        HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));  // the call is synchronous, like the CPU reference
-    g_last_outputs = B;
-    g_pass_serial++;
-    g_last_logits_host = s->logits;
-    g_last_logits_dev = d_logits;
-    g_last_vocab = V;
+    HIP_CHECK(hipMemcpyAsync(out, d_out, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    return 0;
 }
 
 const int* nvllm_last_argmax(int* num_outputs) {
@@ -566,16 +799,22 @@ static void prepare_rows(const float* logits_dev, int rows, int V, float tempera
     HIP_CHECK(hipStreamSynchronize(rt().stream));
 }
 
-// one prepared row -> token, with the reference's coin
-static int pick_from_row(Sampler* s, int row, int V) {
+// one prepared row -> token, with the reference's coin.  `host_probs`: the row's probabilities when
+// the caller already has them on the host (else they are fetched if the whole row is needed).
+static int pick_from_row(Sampler* s, int row, int V, const float* host_probs) {
     const float coin = (float)rand() / (float)RAND_MAX;   // sampler.c:124
     const bool nucleus = s->topp > 0.f && s->topp < 1.f;
     if (nucleus && g_count_host[row] <= SAMPLE_CAP)
         return nucleus_pick(g_cand_host + (size_t)row * SAMPLE_CAP, g_count_host[row], s->topp, coin);
     // whole-row path: plain sampling (sampler.c:126-134), or a nucleus too wide for the candidate buffer
-    float* pr = (float*)malloc((size_t)V * sizeof(float));
-    HIP_CHECK(hipMemcpyAsync(pr, g_probs_dev + (size_t)row * V, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
-    HIP_CHECK(hipStreamSynchronize(rt().stream));
+    float* fetched = nullptr;
+    const float* pr = host_probs;
+    if (!pr) {
+        fetched = (float*)malloc((size_t)V * sizeof(float));
+        HIP_CHECK(hipMemcpyAsync(fetched, g_probs_dev + (size_t)row * V, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
+        HIP_CHECK(hipStreamSynchronize(rt().stream));
+        pr = fetched;
+    }
     int tok = V - 1;
     if (!nucleus) {
         float cdf = 0.0f;
@@ -597,52 +836,59 @@ static int pick_from_row(Sampler* s, int row, int V) {
             }
         tok = nucleus_pick(s->probindex, n, s->topp, coin);
     }
-    free(pr);
+    free(fetched);
     return tok;
 }
 
+// Reference src/sampler.c:84-140.  Which memory answers depends on the hand-off mode:
+//   NVLLM_LOGITS_HOST    the row the caller passes is host memory that the forward pass filled and the
+//                        caller may have edited since (logit bias, banned tokens ...): it is READ as it
+//                        stands, and with a temperature it is rewritten to probabilities, like the
+//                        reference's in-place softmax (sampler.c:100-121).
+//   NVLLM_LOGITS_ARGMAX  RunState.logits was never filled; a pointer to row k of it only NAMES output k
+//                        of the most recent pass, whose logits are still in HBM.
 int sample(Sampler* s, float* logits) {
     ensure_init();
     const int V = s->vocab_size;
-    if (s->temperature != 0.0f) {
-        if (g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
-            const size_t d = (size_t)(logits - g_last_logits_host);
-            if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) {
-                // a row of the most recent forward pass: its logits are still in HBM
-                if (!g_tp_full_valid) {   // ... as vocabulary slices on the ranks: every rank makes this call
-                    tp_gather_logits(const_cast<float*>(g_last_logits_dev), g_tp_local, g_last_outputs, g_tp_slice, V);
-                    g_tp_full_valid = true;
-                }
-                if (g_prep_serial != g_pass_serial || g_prep_temp != s->temperature || g_prep_topp != s->topp) {
-                    prepare_rows(g_last_logits_dev, g_last_outputs, V, s->temperature, s->topp);
-                    g_prep_serial = g_pass_serial;
-                    g_prep_temp = s->temperature;
-                    g_prep_topp = s->topp;
-                }
-                return pick_from_row(s, (int)(d / (size_t)V), V);
-            }
-        }
-        // any other host row: upload it and prepare it alone
-        float* dev = (float*)ws_get(WS_SAMPLE, (size_t)V * sizeof(float));
-        HIP_CHECK(hipMemcpyAsync(dev, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice, rt().stream));
-        prepare_rows(dev, 1, V, s->temperature, s->topp);
-        g_prep_serial = -1;   // the prepared buffers no longer describe the last pass
-        return pick_from_row(s, 0, V);
-    }
-    // a row of the most recent forward pass: answered from the arg-max the GPU already computed
-    if (g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
+    int row = -1;   // output row of the most recent forward pass that `logits` names, if any
+    if (rt().logits_mode == NVLLM_LOGITS_ARGMAX && g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
         const size_t d = (size_t)(logits - g_last_logits_host);
-        if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) return g_argmax_host[d / (size_t)V];
+        if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) row = (int)(d / (size_t)V);
     }
-    // any other host row: upload and reduce with the same kernel
-    float* dev = (float*)ws_get(WS_MISC, (size_t)V * sizeof(float) + 256);
-    int* dres = (int*)ws_get(WS_MISC2, 256);
+    if (s->temperature == 0.0f) {
+        if (row >= 0) return g_argmax_host[row];   // the arg-max the GPU already computed
+        // sampler.c:86-97 on the caller's row: first index of the maximum
+        int best = 0;
+        float best_v = logits[0];
+        for (int i = 1; i < V; i++)
+            if (logits[i] > best_v) {
+                best = i;
+                best_v = logits[i];
+            }
+        return best;
+    }
+    // temperature > 0: softmax and the nucleus filter run on the GPU
+    if (row >= 0) {
+        if (!g_tp_full_valid) {   // the logits are vocabulary slices on the ranks: every rank makes this call
+            tp_gather_logits(const_cast<float*>(g_last_logits_dev), g_tp_local, g_last_outputs, g_tp_slice, V);
+            g_tp_full_valid = true;
+        }
+        if (g_prep_serial != g_pass_serial || g_prep_temp != s->temperature || g_prep_topp != s->topp) {
+            prepare_rows(g_last_logits_dev, g_last_outputs, V, s->temperature, s->topp);   // all rows of the pass at once
+            g_prep_serial = g_pass_serial;
+            g_prep_temp = s->temperature;
+            g_prep_topp = s->topp;
+        }
+        return pick_from_row(s, row, V, nullptr);
+    }
+    // a host row: upload it, prepare it alone, hand the probabilities back in place
+    float* dev = (float*)ws_get(WS_SAMPLE, (size_t)V * sizeof(float));
     HIP_CHECK(hipMemcpyAsync(dev, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice, rt().stream));
-    launch_argmax(dres, dev, 1, V);
-    int res = 0;
-    HIP_CHECK(hipMemcpyAsync(&res, dres, sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+    prepare_rows(dev, 1, V, s->temperature, s->topp);
+    g_prep_serial = -1;   // the prepared buffers no longer describe the last pass
+    HIP_CHECK(hipMemcpyAsync(logits, g_probs_dev, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
     HIP_CHECK(hipStreamSynchronize(rt().stream));
-    return res;
+    return pick_from_row(s, 0, V, logits);
 }
 
 }  // extern "C"

@@ -70,13 +70,18 @@ class ModelShape:
 _CHUNK = 1 << 24
 
 
-def _write_random(f, n: int, rng: np.random.Generator, span: int, denom: float, dtype) -> None:
-    """n values k/denom with k uniform in [-span, span], streamed in chunks."""
+def _write_random(f, n: int, rng: np.random.Generator, span: int, denom: float, dtype, noise=None) -> None:
+    """n values k/denom with k uniform in [-span, span], streamed in chunks.  With a
+    `noise` generator every value also gets a relative perturbation of about 1e-4, which
+    takes it off the fp16 grid (fp32 files only)."""
     done = 0
     while done < n:
         m = min(_CHUNK, n - done)
         k = rng.integers(-span, span + 1, size=m, dtype=np.int16)
-        (k.astype(np.float32) / np.float32(denom)).astype(dtype).tofile(f)
+        v = k.astype(np.float32) / np.float32(denom)
+        if noise is not None:
+            v = v + noise.standard_normal(m).astype(np.float32) * np.float32(span / denom * 1e-4)
+        v.astype(dtype).tofile(f)
         done += m
 
 
@@ -87,38 +92,44 @@ def _write_norm(f, n: int, rng: np.random.Generator, dtype) -> None:
 
 
 def write_model(path: str, shape: ModelShape, seed: int = 0, dtype: str = "f16",
-                shared: bool = False, rope_tail: bool = False, progress=None) -> int:
+                shared: bool = False, rope_tail: bool = False, progress=None, exact16: bool = True) -> int:
     """Write a random-init model file; returns its size in bytes.
 
     Matrices: k/4096 with |k| <= 82 (about +-0.02); embedding (and a separate
     classifier): k/128 with |k| <= 64 (about +-0.5); norm gains 1 + k/64.
     ``rope_tail`` appends the legacy llama2.c RoPE tables (fp32 shared files only).
     ``progress(name)`` is called after every tensor kind (large files take a while).
+    ``exact16=False`` (fp32 files) perturbs every matrix value so that fp16 cannot hold it,
+    like the weights of a trained fp32 checkpoint.
     """
     progress = progress or (lambda name: None)
     np_dtype = {"f16": np.float16, "f32": np.float32}[dtype]
     D, F, L, V = shape.dim, shape.hidden_dim, shape.n_layers, shape.vocab_size
     QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
     rng = np.random.Generator(np.random.PCG64(seed))
+    noise = None
+    if not exact16:
+        assert dtype == "f32", "only an fp32 file can hold values off the fp16 grid"
+        noise = np.random.Generator(np.random.PCG64(seed + 104729))
     tmp = path + ".tmp"
     with open(tmp, "wb") as f:
         f.write(shape.header())
-        _write_random(f, V * D, rng, 64, 128.0, np_dtype)              # token_embedding_table
+        _write_random(f, V * D, rng, 64, 128.0, np_dtype, noise)       # token_embedding_table
         for _ in range(L):
             _write_norm(f, D, rng, np_dtype)                           # rms_att_weight
         for name, n in (("wq", D * QD), ("wk", D * KD), ("wv", D * KD), ("wo", QD * D)):
             for _ in range(L):
-                _write_random(f, n, rng, 82, 4096.0, np_dtype)
+                _write_random(f, n, rng, 82, 4096.0, np_dtype, noise)
             progress(name)
         for _ in range(L):
             _write_norm(f, D, rng, np_dtype)                           # rms_ffn_weight
         for name, n in (("w_gate", D * F), ("w_down", F * D), ("w_up", D * F)):
             for _ in range(L):
-                _write_random(f, n, rng, 82, 4096.0, np_dtype)
+                _write_random(f, n, rng, 82, 4096.0, np_dtype, noise)
             progress(name)
         _write_norm(f, D, rng, np_dtype)                               # rms_final_weight
         if not shared:
-            _write_random(f, V * D, rng, 64, 2048.0, np_dtype)         # lm_head
+            _write_random(f, V * D, rng, 64, 2048.0, np_dtype, noise)  # lm_head
         if rope_tail:
             assert dtype == "f32" and shared
             np.zeros(shape.max_seq_len * shape.head_dim, np.float32).tofile(f)

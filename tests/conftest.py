@@ -42,12 +42,12 @@ def tmp_models(tmp_path_factory):
     d = tmp_path_factory.mktemp("models")
     cache = {}
 
-    def get(name, seed=1, dtype="f16", shared=False, **over):
-        key = (name, seed, dtype, shared, tuple(sorted(over.items())))
+    def get(name, seed=1, dtype="f16", shared=False, rope_tail=False, exact16=True, **over):
+        key = (name, seed, dtype, shared, rope_tail, exact16, tuple(sorted(over.items())))
         if key not in cache:
             shape = synth.ModelShape.named(name, **over)
             path = str(d / f"{name}_{seed}_{dtype}_{int(shared)}_{len(cache)}.bin")
-            synth.write_model(path, shape, seed=seed, dtype=dtype, shared=shared)
+            synth.write_model(path, shape, seed=seed, dtype=dtype, shared=shared, rope_tail=rope_tail, exact16=exact16)
             cache[key] = (path, shape)
         return cache[key]
 

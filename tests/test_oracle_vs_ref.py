@@ -78,10 +78,13 @@ def test_allocator_offsets_kv_attention(oracle, ref):
     assert outs[0][3] == outs[1][3]
 
 
-@pytest.mark.parametrize("name,chunk,dtype,shared", [("tiny", 16, "f16", False), ("tiny", 5, "f32", True),
-                                                      ("tiny-mha48", 1000, "f16", True), ("tiny", 3, "f32", False)])
-def test_forward_pass_and_scheduler(oracle, ref, tmp_models, name, chunk, dtype, shared):
-    path, shape = tmp_models(name, seed=4, dtype=dtype, shared=shared)
+@pytest.mark.parametrize("name,chunk,dtype,shared,extra", [
+    ("tiny", 16, "f16", False, {}), ("tiny", 5, "f32", True, {}), ("tiny-mha48", 1000, "f16", True, {}),
+    ("tiny", 3, "f32", False, {}),
+    ("tiny", 16, "f32", True, dict(rope_tail=True, exact16=False)),    # like a trained llama2.c file: values off the fp16 grid
+    ("tiny", 7, "f32", False, dict(exact16=False))])
+def test_forward_pass_and_scheduler(oracle, ref, tmp_models, name, chunk, dtype, shared, extra):
+    path, shape = tmp_models(name, seed=4, dtype=dtype, shared=shared, **extra)
     prompts = synth.make_requests(4, 2, 45, shape.vocab_size, seed=8)
     kw = dict(n_new=18, arrivals=[0, 1, 1, 7], collect_logits=True, chunk_size=chunk, temperature=0.0)
     a = util.run_engine(oracle, path, prompts, **kw)
@@ -93,6 +96,33 @@ def test_forward_pass_and_scheduler(oracle, ref, tmp_models, name, chunk, dtype,
             np.testing.assert_array_equal(sa[key], sb[key])
     for x, y in zip(a["histories"], b["histories"]):
         np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("temperature,topp", [(0.8, 0.9), (1.3, 0.5), (1.0, 1.0), (0.5, 0.0), (2.0, 0.99)])
+def test_sampler_with_temperature_matches_the_reference(oracle, ref, temperature, topp):
+    """sample() beyond greedy (reference src/sampler.c:41-139): in-place temperature and softmax,
+    libc rand() coin, plain sampling or the nucleus (cutoff, qsort, cumulative walk).  Same seed,
+    same rows, one library after the other (both draw from the process-wide rand()): the tokens
+    and the rows they leave behind must be identical."""
+    V = 1500
+    r = rng(int(temperature * 100 + topp * 10))
+    rows = (r.standard_normal((40, V)) * 3).astype(np.float32)
+    rows[5, :] = 0.0                     # a flat row: every probability equals the cutoff region
+    rows[6, 17] = 40.0                   # a one-token nucleus
+    rows[7, [3, 4]] = 12.0               # equal probabilities inside the nucleus
+    res = {}
+    for lib in (oracle, ref):
+        smp = capi.Sampler()
+        lib.build_sampler(C.byref(smp), V, temperature, topp, 4242)
+        toks, left = [], []
+        for k in range(rows.shape[0]):
+            row = rows[k].copy()
+            toks.append(lib.sample(C.byref(smp), row.ctypes.data_as(C.POINTER(C.c_float))))
+            left.append(row)
+        res[lib.kind] = (toks, np.stack(left))
+    assert res["oracle"][0] == res["ref"][0]
+    np.testing.assert_array_equal(res["oracle"][1], res["ref"][1])
+    assert len(set(res["oracle"][0])) > 3
 
 
 def test_allocation_trace_of_a_64_sequence_run(oracle, ref, tmp_models):
