@@ -15,7 +15,7 @@ LOGITS_TOL = 2e-2   # the bar stated for this path (max-abs, fp16 weights, fp32 
 
 @pytest.fixture(scope="module")
 def tinyllama(tmp_path_factory):
-    shape = synth.ModelShape.named("tinyllama-1.1b", max_seq_len=512)
+    shape = synth.ModelShape.named("tinyllama-1.1b", max_seq_len=2048)
     path = str(tmp_path_factory.mktemp("full") / "tinyllama.bin")
     synth.write_model(path, shape, seed=0)
     return path, shape
@@ -59,3 +59,73 @@ def test_chunked_prefill_and_decode_at_the_benchmark_shape(hip, oracle, tinyllam
     o = util.run_engine(oracle, path, prompts, **kw)
     g = util.run_engine(hip, path, prompts, **kw)
     _compare(g, o, LOGITS_TOL / 10)
+
+
+def _kv_close(g, o, fp16_pool):
+    """K/V rows left in the pool.  fp32 rows are copies of the projection's fp32 results (summation
+    order away from the oracle's).  fp16 pages: the first layer's rows depend on the embedding and the
+    weights alone, so they are the fp16 roundings of the oracle's values (the neighbouring fp16 number
+    where the two fp32 results straddle a rounding boundary); deeper layers see attention over
+    rounded K/V, which the fp32 oracle does not, and are held to the tolerance of the logits."""
+    for (gk, gv), (ok, ov) in zip(g["kv"], o["kv"]):
+        for a, b in ((gk, ok), (gv, ov)):
+            assert a.shape == b.shape and a.shape[1] > 0
+            scale = max(1.0, float(np.abs(b).max()))
+            if fp16_pool:
+                b16 = np.clip(b, -65504, 65504).astype(np.float16).astype(np.float32)
+                # one fp16 step of the value, plus the fp32 summation-order error of the projection itself
+                # (which is many fp16 steps of a value that happens to lie near zero)
+                bound = np.maximum(np.abs(b16[0]), 2.0 ** -14) * 2.0 ** -10 + 4e-6 * scale
+                worst0 = float((np.abs(a[0] - b16[0]) / bound).max())
+                assert worst0 <= 1.0, worst0
+                assert float(np.mean(a[0] != b16[0])) < 1e-2     # almost every half is the very same number
+                worst = float(np.abs(a - b16).max())
+                assert worst < LOGITS_TOL / 4 * scale, worst
+            else:
+                worst = float(np.abs(a - b).max())
+                assert worst < 2e-5 * scale, worst
+
+
+def test_512_token_chunks_then_decode_beyond_1024_at_the_benchmark_shape(hip, oracle, tinyllama):
+    """What the benchmark times, as a forward pass against the oracle: 1040-token prompts forwarded in
+    512-token chunks (two sequences per pass: 1024 tokens through the dense-contraction projection
+    kernel, both of its wave arrangements, and chunked-prefill attention over fp16 pages), a ragged
+    tail pass, then decode rows at contexts beyond 1024.  Tokens, logits and pool contents."""
+    path, shape = tinyllama
+    prompts = synth.make_requests(2, 1040, 1040, shape.vocab_size, seed=21)
+    kw = dict(n_new=5, collect_logits=True, kv_rows=True, chunk_size=512, temperature=0.0, max_steps=50)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    assert [len(s["tokens"]) for s in o["steps"][:3]] == [1024, 1024, 32]
+    assert max(int(s["pos"].max()) for s in o["steps"]) >= 1040
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(before)
+    worst = _compare(g, o, LOGITS_TOL / 10)
+    _kv_close(g, o, fp16_pool=True)
+    print(f"max |dlogit| = {worst:.3e}")
+
+
+def test_long_context_4k_forward_pass(hip, oracle, tmp_path_factory):
+    """BASELINE.json configs[3]: TinyLlama widths with max_seq_len 4096 -- a 4096-row RoPE table, 256-entry
+    block tables, 3,900-token prompts in 512-token chunks, then decode rows that attend over ~3.9 k keys.
+    Two layers keep the oracle affordable; every kernel sees the full-size shapes."""
+    shape = synth.ModelShape.named("tinyllama-1.1b", max_seq_len=4096, n_layers=2)
+    path = str(tmp_path_factory.mktemp("ctx4k") / "tinyllama_2l_4k.bin")
+    synth.write_model(path, shape, seed=3)
+    prompts = synth.make_requests(2, 3890, 3900, shape.vocab_size, seed=22)
+    kw = dict(n_new=4, collect_logits=True, kv_rows=True, chunk_size=512, temperature=0.0, max_steps=60)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    assert max(int(s["pos"].max()) for s in o["steps"]) >= 3890
+    assert all(len(t) >= 244 for t in o["tables"])               # block tables near their 256-entry capacity
+    for kv_bytes in (2, 4):
+        before = hip.nvllm_get_kv_elem_bytes()
+        hip.nvllm_set_kv_elem_bytes(kv_bytes)
+        try:
+            g = util.run_engine(hip, path, prompts, **kw)
+        finally:
+            hip.nvllm_set_kv_elem_bytes(before)
+        _compare(g, o, LOGITS_TOL / 10 if kv_bytes == 2 else 2e-4)
+        _kv_close(g, o, fp16_pool=kv_bytes == 2)

@@ -20,6 +20,9 @@ TIGHT_TOL = 2e-4     # as for the single-process forward pass
 LOGITS_TOL = 2e-2
 
 GQA = dict(dim=256, hidden_dim=512, n_layers=3, n_heads=8, n_kv_heads=4, vocab_size=600, max_seq_len=160)
+# one layer at the widths of BASELINE.json configs[4] (Llama-2-7B: dim 4096, 32 heads of 128, hidden 11008);
+# a short vocabulary keeps the file and the oracle's classifier small
+LLAMA7B_LAYER = dict(dim=4096, hidden_dim=11008, n_layers=1, n_heads=32, n_kv_heads=32, vocab_size=4000, max_seq_len=256)
 
 
 def _run_and_compare(hip, oracle, path, shape, tol):
@@ -55,6 +58,22 @@ def test_partial_sum_path_with_a_single_rank(hip, oracle, tmp_models):
     assert sum(calls) == 2 * shape.n_layers * shape.dim * sum(len(s["tokens"]) for s in o["steps"])
     # and the fused single-process path is back afterwards
     _run_and_compare(hip, oracle, path, shape, TIGHT_TOL)
+
+
+@pytest.mark.parametrize("kv_bytes", [2, 4])
+def test_7b_width_layer_with_a_single_rank(hip, oracle, tmp_models, kv_bytes):
+    """The tensor-parallel forward pass (partial sums, exchange hook, residual kernel, vocabulary-split
+    classifier) at the 7B widths: head_dim 128, K = 4096 and 11008, 12288-row fused q/k/v."""
+    path, shape = tmp_models("tiny", seed=9, **LLAMA7B_LAYER)
+    cb = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(kv_bytes)
+    assert hip.nvllm_tp_init_custom(0, 1, cb, None) == 0
+    try:
+        _run_and_compare(hip, oracle, path, shape, TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10)
+    finally:
+        hip.nvllm_tp_finalize()
+        hip.nvllm_set_kv_elem_bytes(before)
 
 
 def test_rccl_communicator_of_one_rank(hip, oracle, tmp_models):
@@ -112,20 +131,23 @@ def test_setup_is_refused_twice_and_for_bad_placements(hip):
     (2, 4, dict(hidden_dim=192)),          # "tiny": 4 heads / 2 kv heads of width 16
     (2, 2, GQA),
     (4, 4, GQA),                           # one kv head (two query heads) per rank
+    (2, 4, LLAMA7B_LAYER),                 # 16 heads of 128 and 5504 hidden columns per rank (fp32 rows: the sampled-token
+                                           # comparison draws from probabilities that must agree to ~1e-6)
 ])
 def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_bytes, over):
     """`world` processes, each with its slice of the weights and of the KV pool, the
     exchange staged through the host (gloo); every rank must reproduce the oracle's
     tokens, allocation trace and logits."""
     path, shape = tmp_models("tiny", seed=5, **over)
-    spec = dict(name="tiny", over=over, model_path=path, n_seqs=5, seed=23, n_new=16, chunk=12, kv_bytes=kv_bytes,
-                out_dir=str(tmp_path))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    port = 29620 + world + kv_bytes
+    big = over["dim"] >= 4096
+    spec = dict(name="tiny", over=over, model_path=path, n_seqs=3 if big else 5, seed=23, n_new=8 if big else 16, chunk=12,
+                kv_bytes=kv_bytes, out_dir=str(tmp_path))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else "2")
+    port = 29620 + world + kv_bytes + (40 if big else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "tests", "tp_worker.py"), json.dumps(spec)],
-                         env=env, capture_output=True, text=True, timeout=300)
+                         env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
     for rank in range(world):
         r = json.load(open(tmp_path / f"rank{rank}.json"))

@@ -197,9 +197,30 @@ def op_paged_attention_batch(lib, pool, q, layer, pos, seq_ids, max_seq_len, n_h
     return out
 
 
-def run_engine(lib, model_path, prompts, n_new, arrivals=None, collect_logits=False, **opts):
+def engine_kv_rows(lib, e, n_seqs):
+    """K and V of every position each sequence has been through, read out of the driver's
+    block pool (the library's global g_kv_manager) through the sequences' block tables, in
+    the reference's logical layout: per sequence two arrays [layers, positions, kv_heads * head_dim]."""
+    mgr = capi.KVCacheManager.in_dll(lib.dll, "g_kv_manager")
+    cfg = e.config
+    view = Pool.__new__(Pool)
+    view.lib, view.mgr, view.tables = lib, mgr, []
+    view.geom = (cfg.n_layers, cfg.n_kv_heads, cfg.head_dim)
+    row = cfg.n_kv_heads * cfg.head_dim
+    bs = mgr.block_size
+    pools = [view.dump(which).reshape(cfg.n_layers, mgr.num_blocks * bs, row) for which in ("k", "v")]
+    out = []
+    for i in range(n_seqs):
+        n_pos = e.seq_state(i)["pos"]
+        table = e.block_table(i)
+        rows = np.array([table[p // bs] * bs + p % bs for p in range(n_pos)], dtype=np.int64)
+        out.append(tuple(pl[:, rows, :].copy() for pl in pools))
+    return out
+
+
+def run_engine(lib, model_path, prompts, n_new, arrivals=None, collect_logits=False, kv_rows=False, **opts):
     """Run the N-sequence driver to completion; returns histories, allocation trace
-    and (optionally) the logits of every step."""
+    and (optionally) the logits of every step and the K/V rows left in the pool."""
     n = len(prompts)
     e = capi.Engine(lib, model_path, n, **opts)
     for i, p in enumerate(prompts):
@@ -213,5 +234,7 @@ def run_engine(lib, model_path, prompts, n_new, arrivals=None, collect_logits=Fa
         steps.append(rec)
     out = dict(histories=[e.history(i) for i in range(n)], trace=e.alloc_trace(), steps=steps,
                tables=[e.block_table(i) for i in range(n)], stats=e.stats())
+    if kv_rows:
+        out["kv"] = engine_kv_rows(lib, e, n)
     e.close()
     return out
