@@ -556,6 +556,9 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
 
     StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
                                g_kv_manager.block_size, attn_tokens_per_item(H, KVH));
+    // The reference prints "Block table too small" once per layer and then attends over block ids
+    // read past the table (attention.c:159-162, 285); here the pass ends before any kernel reads them.
+    if (st.table_short) NVLLM_FATAL("transformer_batch: a position lies beyond its sequence's block table (allocate the block first, main.c:320-335)");
     const float2* rope = rope_table(p->rope_theta, hd, st.max_pos + 1);
     const KvPoolView pool = pool_view(&g_kv_manager, KVH, hd);
 

@@ -80,6 +80,7 @@ struct Runtime {
     hipStream_t stream = nullptr;
     int logits_mode = NVLLM_LOGITS_HOST;
     int kv_elem_bytes = 4;
+    bool kv_elem_set = false;   // nvllm_set_kv_elem_bytes was called: the environment default does not apply
     int num_cus = 256;
 };
 Runtime& rt();
@@ -150,9 +151,14 @@ hipEvent_t prof_start_event();   // events of the enclosing ProfScope, or null w
 hipEvent_t prof_stop_event();
 // Every kernel goes through this: on the library stream, with the timing events of the
 // enclosing ProfScope attached to the dispatch itself.
-#define NVLLM_LAUNCH(kernel, grid, block, shmem, ...)                                                   \
-    hipExtLaunchKernelGGL(kernel, grid, block, shmem, ::nvllm::rt().stream, ::nvllm::prof_start_event(), \
-                          ::nvllm::prof_stop_event(), 0, __VA_ARGS__)
+// A launch the runtime rejects (grid, LDS size, missing code object) is reported here, not at some
+// later unrelated call.
+#define NVLLM_LAUNCH(kernel, grid, block, shmem, ...)                                                        \
+    do {                                                                                                     \
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, ::nvllm::rt().stream, ::nvllm::prof_start_event(), \
+                              ::nvllm::prof_stop_event(), 0, __VA_ARGS__);                                   \
+        HIP_CHECK(hipGetLastError());                                                                        \
+    } while (0)
 // While one exists, ProfScope records nothing (and so creates no events): for entry points that
 // must not allocate.
 struct ProfSuppress {

@@ -59,8 +59,11 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
             const int p = pos_arr ? pos_arr[t] : pos0 + t;
             const int sid = seq_ids ? seq_ids[t] : 0;
             const int lb = p / block_size;
-            if (lb + 1 > need[sid]) need[sid] = lb + 1;
             const BlockTable* bt = single ? single : tables[sid];
+            // never read the caller's table past its num_blocks entries
+            const int have = lb + 1 < bt->num_blocks ? lb + 1 : bt->num_blocks;
+            if (have > need[sid]) need[sid] = have;
+            if (lb >= bt->num_blocks) s.table_short = true;
             if (s.write_limit == T && lb >= bt->num_blocks) {
                 // reference attention.c:159-162 (and :123-126): report and stop writing
                 printf("Error: Block table too small! logical_idx=%d, num_blocks=%d\n", lb, bt->num_blocks);
@@ -343,6 +346,9 @@ void paged_attention(float* out, float* q, KVCacheManager* mgr, BlockTable* bloc
     if (num_tokens <= 0) return;
     StepArrays s = stage_step(nullptr, nullptr, nullptr, num_tokens, nullptr, 0, nullptr, block_table, pos,
                               mgr->block_size, attn_tokens_per_item(n_heads, n_kv_heads));
+    // the reference reads block ids past the table here (attention.c:285 has no bounds check);
+    // on the GPU that would be a wild read of the pool, so it ends the process instead
+    if (s.table_short) NVLLM_FATAL("paged attention: a position lies beyond its sequence's block table");
     AttnArgs a{};
     a.q = q;
     a.out_f32 = out;
@@ -369,6 +375,9 @@ void paged_attention_batch(float* out, float* q, KVCacheManager* mgr, BlockTable
     if (num_tokens <= 0) return;
     StepArrays s = stage_step(nullptr, pos_arr, seq_ids, num_tokens, nullptr, 0, block_tables, nullptr, 0,
                               mgr->block_size, attn_tokens_per_item(n_heads, n_kv_heads));
+    // the reference reads block ids past the table here (attention.c:285 has no bounds check);
+    // on the GPU that would be a wild read of the pool, so it ends the process instead
+    if (s.table_short) NVLLM_FATAL("paged attention: a position lies beyond its sequence's block table");
     AttnArgs a{};
     a.q = q;
     a.out_f32 = out;

@@ -183,8 +183,17 @@ static const char* kProfNames[PC_COUNT] = {
 
 // --------------------------------------------------------------------- init
 void ensure_init() {
-    if (g_rt.inited) return;
+    // HIP's current device is per host thread: bind every thread that enters the library once
+    static thread_local bool bound = false;
+    if (g_rt.inited) {
+        if (!bound) {
+            HIP_CHECK(hipSetDevice(g_rt.device));
+            bound = true;
+        }
+        return;
+    }
     HIP_CHECK(hipSetDevice(g_rt.device));
+    bound = true;
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, g_rt.device));
     g_rt.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -195,7 +204,7 @@ void ensure_init() {
         g_stage_used[i] = false;
     }
     const char* kv = getenv("NVLLM_KV_BYTES");
-    if (kv && (atoi(kv) == 2 || atoi(kv) == 4)) g_rt.kv_elem_bytes = atoi(kv);
+    if (kv && !g_rt.kv_elem_set && (atoi(kv) == 2 || atoi(kv) == 4)) g_rt.kv_elem_bytes = atoi(kv);
     noalloc_setup(g_rt.device);
     g_rt.inited = true;
 }
@@ -226,6 +235,7 @@ int nvllm_get_logits_mode(void) { return g_rt.logits_mode; }
 void nvllm_set_kv_elem_bytes(int bytes) {
     if (bytes != 2 && bytes != 4) NVLLM_FATAL("KV element size must be 2 or 4 bytes, got %d", bytes);
     g_rt.kv_elem_bytes = bytes;
+    g_rt.kv_elem_set = true;
 }
 int nvllm_get_kv_elem_bytes(void) { return g_rt.kv_elem_bytes; }
 

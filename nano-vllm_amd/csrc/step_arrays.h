@@ -9,6 +9,7 @@ struct StepArrays {
     int n_seqs;
     int max_pos;      // largest position in the batch
     int write_limit;  // tokens [0, write_limit) get their K/V stored (see attention.c:159-162)
+    bool table_short; // some token's logical block lies beyond its sequence's table
     int* d_tokens;    // [T]        (null when not supplied)
     int* d_pos;       // [T]
     int* d_seq;       // [T]

@@ -296,3 +296,28 @@ def test_contiguous_cache_ops(hip, oracle):
     np.testing.assert_array_equal(outs["hip"][0], outs["oracle"][0])
     np.testing.assert_array_equal(outs["hip"][1], outs["oracle"][1])
     np.testing.assert_allclose(outs["hip"][2], outs["oracle"][2], rtol=0, atol=1e-5)
+
+
+def test_attention_over_a_table_that_is_too_short_ends_the_process(tmp_path):
+    """The reference reads block ids past the end of the table (attention.c:285 has no bounds
+    check).  On the GPU that would be a wild read of the pool: the library neither reads the
+    caller's table past num_blocks nor launches; it reports and aborts."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "short_table.py"
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np\n"
+        "from nvllm_amd import capi\n"
+        "from tests import util\n"
+        "hip = capi.load_hip(); hip.init_ops()\n"
+        "p = util.Pool(hip, 16, 8, 1, 2, 16); p.new_table(1); p.set_table(0, [3])\n"
+        "q = np.zeros((1, 4 * 16), np.float32)\n"
+        "util.op_paged_attention_batch(hip, p, q, 0, [20], [0], 64, 4, 2, 16)\n"   # position 20 needs logical block 1
+        "print('survived')\n")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "survived" not in r.stdout
+    assert "beyond its sequence's block table" in r.stderr
