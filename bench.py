@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
 
 
 # --------------------------------------------------------------------------- helpers
@@ -65,15 +65,16 @@ def algorithmic_bytes_per_decode_step(shape, batch, ctx_lens, kv_bytes, tp_world
 
 def prefill_roofline(shape, tokens_per_s, tp_world=1):
     """Prefill is bound by the matrix cores: flops of the projections per token (2 per weight)
-    against the dense fp16 peak.  Activations enter as fp16 hi + lo, so the matrix cores
-    issue twice the useful flops; `frac` prices the issued ones (whole-job rate over all GPUs
-    that share one model under --tp, per replica otherwise)."""
+    against the dense fp16 peak.  `frac` prices the USEFUL flops; activations enter as fp16
+    hi + lo, so the matrix cores issue twice as many (`issued`, `frac_issued`).  Whole-job
+    rate over all GPUs that share one model under --tp, per replica otherwise."""
     D, F, L = shape.dim, shape.hidden_dim, shape.n_layers
     QD, KD = shape.n_heads * shape.head_dim, shape.n_kv_heads * shape.head_dim
     flops_per_token = 2.0 * L * (2 * D * QD + 2 * D * KD + 3 * D * F)
     useful = flops_per_token * tokens_per_s / 1e12
-    return dict(bound="mfma", achieved=round(useful, 1), issued=round(2 * useful, 1), peak=MFMA_PEAK_TFLOPS * tp_world,
-                unit="TFLOP/s", frac=round(2 * useful / (MFMA_PEAK_TFLOPS * tp_world), 4),
+    peak = MFMA_PEAK_TFLOPS * tp_world
+    return dict(bound="mfma", achieved=round(useful, 1), issued=round(2 * useful, 1), peak=peak,
+                unit="TFLOP/s", frac=round(useful / peak, 4), frac_issued=round(2 * useful / peak, 4),
                 note="projection flops only; tokens/s includes attention, host scheduling and the decode rows batched with the chunks")
 
 
@@ -157,13 +158,26 @@ def ensure_model(path, shape, seed, env):
     env.barrier()
 
 
-def run_gpu(args, env, shape, model_path):
+def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps=None, profile_steps=None):
+    """One measured run.  The keyword overrides serve the `variants` block (same workload with the
+    reference's fp32 pool rows, or with the logits rows copied to the host every step)."""
     from nvllm_amd import capi, synth
+    import copy
+    args = copy.copy(args)
+    if kv_bytes is not None:
+        args.kv_bytes = kv_bytes
+    if logits_host is not None:
+        args.logits_host = logits_host
+    if steps is not None:
+        args.steps = steps
+    if profile_steps is not None:
+        args.profile_steps = profile_steps
     lib = capi.load_hip()           # raises if the HIP library is not built: no fall-back
     lib.nvllm_set_device(env.local_rank)
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
     lib.nvllm_set_logits_mode(0 if args.logits_host else 1)   # default: only token ids return to the host
-    if args.tp:
+    if args.tp and not getattr(run_gpu, "_tp_up", False):
+        run_gpu._tp_up = True
         # one RCCL communicator over all ranks, owned by the library: its all-reduces run on the
         # library's stream.  (With one rank the same code path runs, the sums have one term.)
         ident = None
@@ -233,11 +247,10 @@ def run_gpu(args, env, shape, model_path):
                 prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, total_ms=ms.value,
                                                              bytes=by.value, flops=fl.value)
     hist = eng.history(0)[-4:].tolist()
+    forward_ms = st.decode_step_seconds / max(1, args.warmup + args.steps) * 1e3   # inside transformer_batch only
     eng.close()
-    if args.tp:
-        lib.nvllm_tp_finalize()
     return dict(elapsed=elapsed, prefill_s=prefill_s, prefill_tokens=prefill_tokens, step_bytes=step_bytes,
-                prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist)
+                prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist, forward_ms=forward_ms)
 
 
 def cpu_baseline(args, shape, model_path):
@@ -274,6 +287,7 @@ def cpu_baseline(args, shape, model_path):
         os.close(saved)
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     return dict(value=round(B * args.cpu_steps / dt, 3), unit="tokens/s", cores=cores, kind=kind,
+                context_tokens=[2, 2 + args.cpu_steps], batch=B, kv_elem_bytes=4,
                 sample=f"{args.cpu_steps} decode steps of {B} sequences at context 2-{2 + args.cpu_steps} "
                        f"({B * args.cpu_steps} tokens, {dt:.1f} s wall, OpenMP)")
 
@@ -297,6 +311,8 @@ def main():
                     help="copy the full fp32 logits rows to the host every step, as the reference's contract has it "
                          "(the PCIe-inclusive variant; not the headline number)")
     ap.add_argument("--profile-steps", type=int, default=8)
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` block (N = 1 only: the same workload with the fp32 row pool and with logits rows to the host)")
     ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
     args = ap.parse_args()
@@ -319,6 +335,20 @@ def main():
 
     r = run_gpu(args, env, shape, model_path)
     N, K, B = env.world, args.steps, args.batch
+    variants = None
+    if env.world == 1 and not args.tp and not args.no_variants and not args.logits_host and args.kv_bytes == 2:
+        # the library's drop-in defaults, on the same workload: the reference's fp32 pool rows, and the
+        # reference's result contract (full logits rows in host memory, src/main.c:377; sample() then scans
+        # the host row).  Shorter timed regions; never the headline value.
+        variants = {}
+        vk = max(8, min(K, 16))
+        for name, kw in (("fp32_kv_pool", dict(kv_bytes=4)), ("logits_rows_to_host", dict(logits_host=True)),
+                         ("fp32_kv_pool_and_logits_rows_to_host", dict(kv_bytes=4, logits_host=True))):
+            v = run_gpu(args, env, shape, model_path, steps=vk, profile_steps=0, **kw)
+            variants[name] = dict(value=round(B * vk / v["elapsed"], 1), unit="tokens/s", ms_per_step=round(v["elapsed"] / vk * 1e3, 4),
+                                  forward_ms_per_step=round(v["forward_ms"], 4), steps=vk, mean_context=v["ctx"],
+                                  kv_elem_bytes=kw.get("kv_bytes", 2),
+                                  result_handoff="logits rows to host (PCIe-inclusive)" if kw.get("logits_host") else "token ids only")
     ms_per_step = r["elapsed"] / K * 1e3
     value = B * (1 if args.tp else N) * K / r["elapsed"]
     prefill_tps = env.reduce(r["prefill_tokens"] / r["prefill_s"], "MAX" if args.tp else "SUM")
@@ -345,6 +375,9 @@ def main():
                 return dict(bound="hbm", kernel=name, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 4),
                             traffic=pmc.get(name, {}).get("hbm_bytes_per_launch"),
+                            # PMC counters need their own rocprofv3 passes: the figure is replayed from the
+                            # tracked file that tools/gpu_evidence.sh wrote for this workload, not measured in this run
+                            traffic_source=(f"profiles/{PMC_TRAFFIC_FILE} (replayed)" if name in pmc else None),
                             avg_kernel_us=round(avg_ms * 1e3, 2),   # dispatch begin -> end, HIP events of the launch
                             launches=d["launches"],
                             algorithmic_bytes_per_launch=int(d["bytes"] / d["launches"]),
@@ -371,8 +404,10 @@ def main():
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
             "cpu_baseline": cpu,
+            "variants": variants,
             "step_hbm": {"algorithmic_bytes_per_step": int(r["step_bytes"]), "achieved_GBps": round(step_gbs, 1),
                          "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
+            "forward_ms_per_step": round(r["forward_ms"], 4),
             "prefill_tokens_per_s": round(prefill_tps, 1),
             "prefill_roofline": prefill_roofline(shape, prefill_tps, env.world if args.tp else 1),
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2),
@@ -382,6 +417,9 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    if args.tp:
+        from nvllm_amd import capi
+        capi.load_hip().nvllm_tp_finalize()
     env.close()
 
 

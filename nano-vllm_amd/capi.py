@@ -175,7 +175,7 @@ DEVICE_TO_HOST, DEVICE_TO_DEVICE, HOST_TO_DEVICE = 0, 1, 2
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-HIP_LIB = os.path.join(PKG_DIR, "libnvllm_hip.so")
+HIP_LIB = os.environ.get("NVLLM_HIP_LIB") or os.path.join(PKG_DIR, "libnvllm_hip.so")   # the override serves A/B builds of the same library
 
 
 def declared_symbols(hip: bool = True):

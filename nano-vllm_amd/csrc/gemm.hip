@@ -45,12 +45,21 @@ namespace nvllm {
 template <int NBW, int TB, int NW, int EPI, typename KVT>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
-    constexpr int RW = 4;              // weight ring depth (K-steps in flight)
-    constexpr int RA = 2;              // activation ring depth
+#ifndef NVLLM_RW
+#define NVLLM_RW 4
+#endif
+#ifndef NVLLM_RA
+#define NVLLM_RA 2
+#endif
+    constexpr int RW = NVLLM_RW;       // weight ring depth (K-steps in flight)
+    constexpr int RA = NVLLM_RA;       // activation ring depth
     constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
     constexpr int ITEMS = 2 * TB * 64; // float4 results per round
     constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
-    __shared__ f4_t red[NW][2][TB][64];
+    // the waves' partial tiles, all row blocks at once: red[wave][row block][token block][lane]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    typedef f4_t RedTile[NBW][TB][64];
+    RedTile* red = reinterpret_cast<RedTile*>(lds_dyn);
     __shared__ float s_rinv[TB * 16];
     __shared__ float s_part[(NW * 64) / (TB * 16)][TB * 16];
     __shared__ float s_ss[2][TB * 16];
@@ -175,40 +184,40 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         pf_pos = ep.pos[t];
         pf_row = ep.kv_row[t];
     }
-    // ---- 1. sum the waves' partial tiles through LDS, two row blocks per round.
-    // Afterwards thread `e` (item e = threadIdx.x + q * NW*64) owns, per round h, the
-    // float4 for token t(e) and features n(h, e) .. n+3.
+    // ---- 1. sum the waves' partial tiles through LDS: every wave stores all its tiles, ONE
+    // barrier, then thread `e` (item e = threadIdx.x + q * NW*64) collects, per round h (two row
+    // blocks), the float4 for token t(e) and features n(h, e) .. n+3, in wave order.
     f4_t v[ROUNDS][IPT];
 #pragma unroll
+    for (int i = 0; i < NBW; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++) red[wave][i][j][lane] = acc[i][j];
+    __syncthreads();
+    if (ep.ss_in != nullptr && threadIdx.x < TB * 16) {
+        // 1/rms per token from the slices gathered at the top (s_part: visible since the barrier
+        // above; s_rinv is read by the epilogue after at least one more barrier)
+        constexpr int PARTS = (NW * 64) / (TB * 16);
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
+        s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
+    }
+#pragma unroll
     for (int h = 0; h < ROUNDS; h++) {
-        __syncthreads();
-        if (h == 0 && ep.ss_in != nullptr && threadIdx.x < TB * 16) {
-            // 1/rms per token from the slices gathered at the top (visible since the barrier
-            // above; read by the epilogue after the barriers below)
-            constexpr int PARTS = (NW * 64) / (TB * 16);
-            float ss = 0.f;
-#pragma unroll
-            for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
-            s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < TB; j++) red[wave][i][j][lane] = acc[2 * h + i][j];
-        __syncthreads();
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const int e = threadIdx.x + q * NW * 64;
             f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
             if (e < ITEMS) {
                 const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                sum = red[0][i][j][l];
+                sum = red[0][2 * h + i][j][l];
 #pragma unroll
-                for (int wv = 1; wv < NW; wv++) sum += red[wv][i][j][l];
+                for (int wv = 1; wv < NW; wv++) sum += red[wv][2 * h + i][j][l];
             }
             v[h][q] = sum;
         }
     }
+    __syncthreads();   // everybody has read the partial tiles (the epilogue reuses the array) and s_rinv is visible
     NVLLM_STAMP(4, v[ROUNDS - 1][IPT - 1][0]);
     // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
     const unsigned tile_id = blockIdx.z * gridDim.x + blockIdx.x;
@@ -412,26 +421,42 @@ int gemm_pick_ksplit(int N, int K, int T) {
 // arrival counters: zero when allocated, every launch leaves them zero again
 static unsigned* g_counters = nullptr;
 #ifdef NVLLM_STAMPS
-unsigned long long* g_gemm_stamps = nullptr;   // set by the diagnostic harness
+// Diagnostic builds only (tools/gemm_stamps.py): launch i of the projection kernel records its
+// workgroups' clock readings in slot i % cap of the harness's buffer, STAMP_WGS x 8 words per slot.
+constexpr int STAMP_WGS = 1024;
+static unsigned long long* g_gemm_stamps = nullptr;
+static int g_stamp_cap = 0, g_stamp_next = 0;
+extern "C" void nvllm_debug_set_gemm_stamps(unsigned long long* buf, int cap) {
+    g_gemm_stamps = buf;
+    g_stamp_cap = cap;
+    g_stamp_next = 0;
+}
+extern "C" int nvllm_debug_gemm_stamp_launches(void) { return g_stamp_next; }
 #endif
 constexpr int MAX_COUNTERS = 1 << 16;
 
+// One instantiation: its dynamic LDS is the waves' partial tiles (1 KiB per wave, row block and
+// token block); sizes beyond the 64 KiB default are enabled once.
+template <int NBW, int TB, int NW, int EPI, typename KVT>
+static void launch_k(const GemmArgs& a, dim3 grid) {
+    constexpr int shmem = NW * NBW * TB * 64 * 16;
+    static_assert(shmem <= 144 * 1024, "partial tiles must fit the CU's LDS next to the static arrays");
+    static bool enabled = false;
+    if (shmem > 64 * 1024 && !enabled) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<NBW, TB, NW, EPI, KVT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+        enabled = true;
+    }
+    NVLLM_LAUNCH((k_gemm<NBW, TB, NW, EPI, KVT>), grid, dim3(NW * 64), shmem, a);
+}
+
 template <int NBW, int TB, typename KVT>
 static void launch_tb(const GemmArgs& a, dim3 grid) {
-    const dim3 block(GEMM_NW * 64);
     switch (a.e.kind) {
-        case GemmEpilogue::F32:
-            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>), grid, block, 0, a);
-            break;
-        case GemmEpilogue::SWIGLU_A16:
-            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>), grid, block, 0, a);
-            break;
-        case GemmEpilogue::RESID_A16:
-            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>), grid, block, 0, a);
-            break;
-        default:
-            NVLLM_LAUNCH((k_gemm<NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>), grid, block, 0, a);
-            break;
+        case GemmEpilogue::F32: launch_k<NBW, TB, GEMM_NW, GemmEpilogue::F32, KVT>(a, grid); break;
+        case GemmEpilogue::SWIGLU_A16: launch_k<NBW, TB, GEMM_NW, GemmEpilogue::SWIGLU_A16, KVT>(a, grid); break;
+        case GemmEpilogue::RESID_A16: launch_k<NBW, TB, GEMM_NW, GemmEpilogue::RESID_A16, KVT>(a, grid); break;
+        default: launch_k<NBW, TB, GEMM_NW, GemmEpilogue::ROPE_KV, KVT>(a, grid); break;
     }
 }
 
@@ -530,7 +555,11 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     a.ksplit = ks;
     a.counters = wsp ? wsp->counters : g_counters;
 #ifdef NVLLM_STAMPS
-    a.stamps = g_gemm_stamps;
+    a.stamps = nullptr;
+    if (g_gemm_stamps && g_stamp_cap > 0) {
+        a.stamps = g_gemm_stamps + (size_t)(g_stamp_next % g_stamp_cap) * STAMP_WGS * 8;
+        g_stamp_next++;
+    }
 #endif
     a.slab = nullptr;
     if (ks > 1) {
@@ -541,14 +570,14 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
     if (nbw == 6) {
-        NVLLM_LAUNCH((k_gemm<6, 2, GEMM_NW, GemmEpilogue::SWIGLU_A16, float>), grid, dim3(GEMM_NW * 64), 0, a);
+        launch_k<6, 2, GEMM_NW, GemmEpilogue::SWIGLU_A16, float>(a, grid);
     } else if (nbw == 2) {   // token-split configuration
         if (kv16) { if (TB == 1) launch_tb<2, 1, __half>(a, grid); else launch_tb<2, 2, __half>(a, grid); }
         else { if (TB == 1) launch_tb<2, 1, float>(a, grid); else launch_tb<2, 2, float>(a, grid); }
     } else if (epi.kind == GemmEpilogue::F32 && TB == 4 && ks == 1 && (long)tiles_n * tiles_t > rt().num_cus) {
         // more tiles than CUs (the classifier): four waves per workgroup, so that two
         // workgroups share a CU and one's start-up overlaps the other's streaming (41 -> 35.5 us)
-        NVLLM_LAUNCH((k_gemm<GEMM_NBW, 4, 4, GemmEpilogue::F32, float>), grid, dim3(4 * 64), 0, a);
+        launch_k<GEMM_NBW, 4, 4, GemmEpilogue::F32, float>(a, grid);
     } else if (kv16) {
         if (TB == 1) launch_tb<GEMM_NBW, 1, __half>(a, grid);
         else if (TB == 2) launch_tb<GEMM_NBW, 2, __half>(a, grid);

@@ -860,15 +860,15 @@ int sample(Sampler* s, float* logits) {
     }
     if (s->temperature == 0.0f) {
         if (row >= 0) return g_argmax_host[row];   // the arg-max the GPU already computed
-        // sampler.c:86-97 on the caller's row: first index of the maximum
-        int best = 0;
-        float best_v = logits[0];
-        for (int i = 1; i < V; i++)
-            if (logits[i] > best_v) {
-                best = i;
-                best_v = logits[i];
-            }
-        return best;
+        // sampler.c:86-97 on the caller's row: the strict '>' scan from index 0 ends on the first
+        // index that attains the maximum.  Two passes the compiler can vectorise: the maximum (a
+        // NaN never wins a '>' and an initial NaN is never displaced, as in the reference), then
+        // its first occurrence.
+        float top = logits[0];
+        for (int i = 1; i < V; i++) top = logits[i] > top ? logits[i] : top;
+        for (int i = 0; i < V; i++)
+            if (logits[i] == top) return i;
+        return 0;   // logits[0] is NaN: the reference's scan never leaves index 0
     }
     // temperature > 0: softmax and the nucleus filter run on the GPU
     if (row >= 0) {
