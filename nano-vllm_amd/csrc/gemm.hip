@@ -494,7 +494,11 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     // Hundreds of tokens (prefill chunks): the contraction is dense enough for the
     // LDS-shared 128 x 128 tiles of gemm_prefill.hip.
     static const int pf_min_t = getenv("NVLLM_GEMM_PREFILL_T") ? atoi(getenv("NVLLM_GEMM_PREFILL_T")) : 256;
-    if (force_ksplit <= 0 && T >= pf_min_t && !wsp) {
+    // ... and already for a wide decode batch (about 128 rows) when the projection is wide enough that its
+    // 128 x 128 tiles occupy most of the chip without a K split (the 7B gate/up projection at batch 128:
+    // 172 tiles, 78 us against 104 us for the streaming kernel in two 64-token groups).
+    const bool wide_decode = T >= 112 && T <= 128 && cdiv(a.NB, 8) * 5 >= rt().num_cus * 3;
+    if (force_ksplit <= 0 && (T >= pf_min_t || wide_decode) && !wsp) {
         ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
         launch_gemm_prefill(a);
         return 1;

@@ -20,8 +20,12 @@ WORKER = textwrap.dedent("""
         work["n"] += len(ids)
     elapsed = bench.timed_steps(env, lambda: None, step, warmup=2, steps=5)
     total = env.reduce(float(work["n"]), "SUM")
+    # the path the tensor-parallel bench uses to hand the communicator id from rank 0 to the others
+    ident = bytes(range(128)) if env.rank == 0 else None
+    got = env.broadcast_bytes(ident, 128)
+    same = env.reduce(1.0 if got == bytes(range(128)) else 0.0, "SUM")
     if env.rank == 0:
-        print(json.dumps({"ids0": ids, "elapsed": elapsed, "total": total, "world": env.world}))
+        print(json.dumps({"ids0": ids, "elapsed": elapsed, "total": total, "world": env.world, "id_ok": same}))
     env.close()
 """) % ROOT
 
@@ -40,6 +44,7 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert r["ids0"] == [0, 2, 4, 6]              # request r -> replica r mod world
     assert r["total"] == 2 * 4 * 7                # every rank ran warmup + steps on its own 4 requests
     assert r["elapsed"] >= 5 * 0.004 * 0.9        # the MAX over ranks: the slow rank's time
+    assert r["id_ok"] == 2.0                      # every rank holds rank 0's 128-byte id
 
 
 def test_shards_partition_the_request_stream():

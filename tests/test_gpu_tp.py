@@ -139,7 +139,7 @@ def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_
     exchange staged through the host (gloo); every rank must reproduce the oracle's
     tokens, allocation trace and logits."""
     path, shape = tmp_models("tiny", seed=5, **over)
-    big = over["dim"] >= 4096
+    big = over.get("dim", 0) >= 4096
     spec = dict(name="tiny", over=over, model_path=path, n_seqs=3 if big else 5, seed=23, n_new=8 if big else 16, chunk=12,
                 kv_bytes=kv_bytes, out_dir=str(tmp_path))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else "2")
