@@ -42,6 +42,13 @@
 
 namespace nvllm {
 
+// Weight tiles are read once per launch: non-temporal loads (a build knob for A/B runs)
+#ifdef NVLLM_W_PLAIN
+#define NVLLM_WLOAD(p) (*(p))
+#else
+#define NVLLM_WLOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <int NBW, int TB, int NW, int EPI, typename KVT>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
         if (s < nsteps) {
             const int kb = kb_of(s);
 #pragma unroll
-            for (int i = 0; i < NBW; i++) w[s][i] = __builtin_nontemporal_load(wp[i] + (size_t)kb * 64);
+            for (int i = 0; i < NBW; i++) w[s][i] = NVLLM_WLOAD(wp[i] + (size_t)kb * 64);
         }
 #pragma unroll
     for (int s = 0; s < RA; s++)
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
                 if (s + RW < nsteps) {
                     const int kbw = kb_of(s + RW);
 #pragma unroll
-                    for (int i = 0; i < NBW; i++) w[r][i] = __builtin_nontemporal_load(wp[i] + (size_t)kbw * 64);
+                    for (int i = 0; i < NBW; i++) w[r][i] = NVLLM_WLOAD(wp[i] + (size_t)kbw * 64);
                 }
                 if (s + RA < nsteps) {
                     const int kba = kb_of(s + RA);
