@@ -135,6 +135,24 @@ void nvllm_tp_finalize(void);
 int  nvllm_tp_rank(void);
 int  nvllm_tp_world(void);
 
+/* --------------------------------------------- the forward pass in two halves */
+/* No counterpart in the reference, whose transformer_batch returns with the results.  A driver
+ * whose scheduling does not depend on the sampled token VALUES (greedy decoding, sequences that
+ * end by length) can keep the GPU busy across steps: enqueue pass n+1 before collecting pass n,
+ * naming for each decode row the output row of pass n whose arg-max it continues with; the GPU
+ * takes those token ids from HBM.  Only in NVLLM_LOGITS_ARGMAX mode (host logits rows belong to
+ * one pass at a time).  Same arguments as transformer_batch (src/model.c:347-419) plus
+ *   token_src[t]  -1: the token id is tokens[t];  k >= 0: it is the arg-max of output row k of
+ *                 the pass enqueued immediately before this one (null = all -1).
+ * Returns a ticket (>= 0), or -1 when the mode does not allow it or num_tokens == 0.  The host
+ * arrays may be reused as soon as the call returns.  At most 4 passes may be in flight. */
+long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
+                           int num_outputs, const int* token_src, Config* p, RunState* s, Weights* w,
+                           BlockTable** block_tables);
+/* Waits for that pass and copies its arg-max indices (min(cap, num_outputs) of them); returns
+ * num_outputs. */
+int nvllm_forward_collect(long ticket, int* argmax_out, int cap);
+
 /* ------------------------------------------------------ N-sequence driver */
 /* The reference's scheduler with the sequence count as a parameter: arrival
  * gating, is_prefill = pos < n_prompt-1, chunked prefill, batch-capacity check,

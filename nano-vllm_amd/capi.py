@@ -152,6 +152,9 @@ _HIP_ONLY = {
     "nvllm_get_logits_mode": (_I, []),
     "nvllm_last_argmax": (c_int_p, [c_int_p]),
     "nvllm_argmax_rows": (_I, [c_int_p, _P, _I, _I, _I]),
+    "nvllm_forward_enqueue": (_L, [c_int_p, _I, c_int_p, c_int_p, c_int_p, _I, c_int_p, C.POINTER(Config),
+                                   C.POINTER(RunState), C.POINTER(Weights), C.POINTER(C.POINTER(BlockTable))]),
+    "nvllm_forward_collect": (_I, [_L, c_int_p, _I]),
     "nvllm_set_kv_elem_bytes": (_V, [_I]),
     "nvllm_get_kv_elem_bytes": (_I, []),
     "nvllm_prof_enable": (_V, [_I]),

@@ -178,6 +178,19 @@ void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const floa
                        ss_tiles);
 }
 
+// Token ids that the host does not know yet: tokens[t] = prev[src[t]] where src[t] >= 0 (prev = the
+// arg-max indices the previous pass left in HBM).
+__global__ __launch_bounds__(256) void k_patch_tokens(int* __restrict__ tokens, const int* __restrict__ src,
+                                                      const int* __restrict__ prev, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T && src[t] >= 0) tokens[t] = prev[src[t]];
+}
+void launch_patch_tokens(int* tokens, const int* src, const int* prev, int T) {
+    if (T <= 0) return;
+    ProfScope ps(PC_EMBED, (double)T * 12.0, 0);
+    NVLLM_LAUNCH(k_patch_tokens, dim3(cdiv(T, 256)), dim3(256), 0, tokens, src, prev, T);
+}
+
 // Rows idx[r] of an fp32 [*, D] table -> rows r of dst (the embedding lookup and the output
 // gather of the forward pass on fp32 weights: reference model.c:352-355, 411-414).
 __global__ __launch_bounds__(256) void k_gather_rows_f32(float* __restrict__ dst, const float* __restrict__ src,

@@ -84,8 +84,20 @@ static bool f32_file_fits_fp16(FILE* f, long start, const std::vector<std::pair<
 }
 
 // State of the most recent forward pass, for sample() and nvllm_last_argmax().
-static int* g_argmax_host = nullptr;   // pinned
-static int g_argmax_cap = 0;
+// Arg-max indices of the passes in flight: a small ring of page-locked arrays, each with the
+// event recorded behind the copy that fills it.  A pass enqueued with nvllm_forward_enqueue owns
+// slot (ticket % PASS_RING) until it is collected; transformer_batch collects at once.
+constexpr int PASS_RING = 4;
+struct PassSlot {
+    int* host = nullptr;
+    int cap = 0;
+    hipEvent_t ev = nullptr;
+    long ticket = -1;
+    int outputs = 0;
+};
+static PassSlot g_pass[PASS_RING];
+static long g_next_ticket = 0;
+static int* g_argmax_host = nullptr;   // the most recent collected pass's indices (one of the ring's arrays)
 static int g_last_outputs = 0;
 static const float* g_last_logits_host = nullptr;
 static const float* g_last_logits_dev = nullptr;
@@ -112,23 +124,43 @@ static void tp_gather_logits(float* full, const float* local, int rows, int slic
     launch_logits_unshard(full, parts, W, rows, slice, V);
 }
 
-// End of a forward pass: results to the host, and what sample() needs to recognise its rows.
-static void finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V) {
-    if (B > g_argmax_cap) {
-        if (g_argmax_host) HIP_CHECK(hipHostFree(g_argmax_host));
-        g_argmax_cap = B + 256;
-        HIP_CHECK(hipHostMalloc((void**)&g_argmax_host, (size_t)g_argmax_cap * sizeof(int), hipHostMallocDefault));
+// End of a forward pass: the copies that carry its results to the host are enqueued behind its
+// kernels and an event behind them; returns the pass's ticket.
+static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V) {
+    const long ticket = g_next_ticket++;
+    PassSlot& slot = g_pass[ticket % PASS_RING];
+    if (slot.ticket >= 0) NVLLM_FATAL("forward pass %ld was never collected: at most %d passes may be in flight", slot.ticket, PASS_RING);
+    if (B > slot.cap) {
+        if (slot.host) HIP_CHECK(hipHostFree(slot.host));
+        slot.cap = B + 256;
+        HIP_CHECK(hipHostMalloc((void**)&slot.host, (size_t)slot.cap * sizeof(int), hipHostMallocDefault));
     }
+    if (!slot.ev) HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
     hipStream_t stream = rt().stream;
-    HIP_CHECK(hipMemcpyAsync(g_argmax_host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (rt().logits_mode == NVLLM_LOGITS_HOST)
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));  // the call is synchronous, like the CPU reference
+    HIP_CHECK(hipEventRecord(slot.ev, stream));
+    slot.ticket = ticket;
+    slot.outputs = B;
     g_last_outputs = B;
     g_pass_serial++;
     g_last_logits_host = s->logits;
     g_last_logits_dev = d_logits;
     g_last_vocab = V;
+    return ticket;
+}
+
+// Wait for a pass's results; its indices stay readable at the returned address until the slot's
+// next use (PASS_RING passes later).
+static const int* collect_pass(long ticket, int* num_outputs) {
+    PassSlot& slot = g_pass[ticket % PASS_RING];
+    if (slot.ticket != ticket) NVLLM_FATAL("forward pass %ld is not in flight", ticket);
+    HIP_CHECK(hipEventSynchronize(slot.ev));
+    slot.ticket = -1;
+    if (num_outputs) *num_outputs = slot.outputs;
+    g_argmax_host = slot.host;
+    return slot.host;
 }
 
 // ---- fp32 files whose values fp16 cannot hold (e.g. a trained llama2.c stories15M.bin) ----
@@ -532,8 +564,12 @@ void transformer(int* tokens, int num_tokens, int pos, Config* p, RunState* s, W
 }
 
 // ------------------------------------------------------- transformer_batch
-void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
-                       int num_outputs, Config* p, RunState* s, Weights* w, BlockTable** block_tables) {
+// One forward pass, enqueued on the library stream; returns its ticket.  `token_src` (optional, one
+// entry per token): -1 = the token id is tokens[t]; k >= 0 = it is the arg-max of output row k of
+// the pass enqueued just before this one, taken on the GPU (the host need not have seen it yet).
+static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
+                         int num_outputs, Config* p, RunState* s, Weights* w, BlockTable** block_tables,
+                         const int* token_src) {
     ensure_init();
     if (!g_paged_mode) {  // model.c:374-377
         printf("Error: Continuous batching requires paged mode.\n");
@@ -542,7 +578,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     ModelPriv* m = (ModelPriv*)w->_data_buffer;
     if (!m) NVLLM_FATAL("transformer_batch: these weights were not produced by this library's load_model");
     const int T = num_tokens, B = num_outputs;
-    if (T <= 0) return;
+    if (T <= 0) return -1;
     if (T > p->max_seq_len || B > p->max_seq_len) NVLLM_FATAL("batch of %d tokens exceeds the workspace (%d)", T, p->max_seq_len);
     // H, KVH, F, QD, KD: what THIS process computes (its tensor-parallel slice; the whole model when world == 1)
     const int D = p->dim, F = m->sh.hidden, hd = p->head_dim, H = m->sh.n_heads, KVH = m->sh.n_kv_heads;
@@ -555,7 +591,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     const float eps = 1e-5f;  // model.c:361,388,396
 
     StepArrays st = stage_step(tokens, pos_arr, seq_ids, T, output_indices, B, block_tables, nullptr, 0,
-                               g_kv_manager.block_size, attn_tokens_per_item(H, KVH));
+                               g_kv_manager.block_size, attn_tokens_per_item(H, KVH), token_src);
     // The reference prints "Block table too small" once per layer and then attends over block ids
     // read past the table (attention.c:159-162, 285); here the pass ends before any kernel reads them.
     if (st.table_short) NVLLM_FATAL("transformer_batch: a position lies beyond its sequence's block table (allocate the block first, main.c:320-335)");
@@ -570,14 +606,15 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
     float* ss_a = ss;                       // sums of squares of x entering an attention block
     float* ss_b = ss + (size_t)T * ssn;     // ... entering an MLP block
     float* d_logits = (float*)ws_get(WS_LOGITS, (size_t)B * V * sizeof(float));
-    int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
+    // the arg-max indices live in a buffer that never moves (the next pass may read them as its tokens)
+    int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(p->max_seq_len + 64) * sizeof(int));
+    if (st.d_tok_src) launch_patch_tokens(st.d_tokens, st.d_tok_src, d_argmax, T);
 
     if (m->f32) {   // fp32 weights: the reference's operator sequence
         forward_f32(st, T, B, p, s, w, pool, rope, d_logits);
         launch_argmax(d_argmax, d_logits, B, V);
         g_tp_full_valid = true;
-        finish_pass(s, d_logits, d_argmax, B, V);
-        return;
+        return finish_pass(s, d_logits, d_argmax, B, V);
     }
 
     // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
@@ -697,7 +734,31 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
         }
     }
 
-    finish_pass(s, d_logits, d_argmax, B, V);
+    return finish_pass(s, d_logits, d_argmax, B, V);
+}
+
+void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
+                       int num_outputs, Config* p, RunState* s, Weights* w, BlockTable** block_tables) {
+    const long ticket = enqueue_pass(tokens, num_tokens, pos_arr, seq_ids, output_indices, num_outputs, p, s, w,
+                                     block_tables, nullptr);
+    if (ticket < 0) return;
+    collect_pass(ticket, nullptr);
+    HIP_CHECK(hipStreamSynchronize(rt().stream));  // the call is synchronous, like the CPU reference
+}
+
+// include/nvllm.h: the forward pass in two halves, for a driver that keeps the GPU busy across steps
+long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices, int num_outputs,
+                           const int* token_src, Config* p, RunState* s, Weights* w, BlockTable** block_tables) {
+    if (rt().logits_mode != NVLLM_LOGITS_ARGMAX) return -1;   // host logits rows belong to one pass at a time
+    if (num_tokens <= 0 || num_outputs < 0 || !tokens || !pos_arr || !seq_ids || !p || !s || !w || !block_tables) return -1;
+    return enqueue_pass(tokens, num_tokens, pos_arr, seq_ids, output_indices, num_outputs, p, s, w, block_tables, token_src);
+}
+
+int nvllm_forward_collect(long ticket, int* argmax_out, int cap) {
+    int n = 0;
+    const int* r = collect_pass(ticket, &n);
+    for (int i = 0; i < n && i < cap; i++) argmax_out[i] = r[i];
+    return n;
 }
 
 // The arg-max kernels of the forward pass on caller-supplied rows (include/nvllm.h).
@@ -705,7 +766,7 @@ int nvllm_argmax_rows(int* out, const float* logits, int num_rows, int vocab_siz
     ensure_init();
     if (num_rows <= 0 || vocab_size <= 0 || !out || !logits) return -1;
     const int B = num_rows, V = vocab_size;
-    int* d_out = (int*)ws_get(WS_ARGMAX, (size_t)(B + 64) * sizeof(int));
+    int* d_out = (int*)ws_get(WS_MISC2, (size_t)(B + 64) * sizeof(int));   // not the passes' own index buffer
     if (slices <= 1) {
         launch_argmax(d_out, logits, B, V);
     } else {

@@ -290,6 +290,7 @@ void launch_resid_prescale(float* x, const float* y, __half* a16, float* ss, con
 // rows idx[r] of an a16 activation (and of its ss table) compacted to rows r = 0..B-1
 void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const float* src_ss, const int* idx,
                        int B, int K, int ss_tiles);
+void launch_patch_tokens(int* tokens, const int* src, const int* prev, int T);
 void launch_gather_rows_f32(float* dst, const float* src, const int* idx, int B, int D);
 void launch_swiglu(float* out, const float* g, const float* u, long n);
 void launch_accum(float* a, const float* b, long n);

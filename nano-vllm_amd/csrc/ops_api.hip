@@ -37,7 +37,7 @@ KvPoolView pool_view(const KVCacheManager* mgr, int n_kv_heads, int head_dim) {
 // pinned region and upload it with a single copy.
 StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids, int T,
                       const int* output_indices, int B, BlockTable** tables, const BlockTable* single,
-                      int pos0, int block_size, int attn_ct) {
+                      int pos0, int block_size, int attn_ct, const int* token_src) {
     StepArrays s{};
     s.T = T;
     s.B = B;
@@ -105,7 +105,7 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
             kv_row[t] = t < s.write_limit ? bt->block_indices[p / block_size] * block_size + p % block_size : -1;
         }
     }
-    const size_t n_ints = (size_t)(tokens ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) + kv_row.size() +
+    const size_t n_ints = (size_t)(tokens ? T : 0) + (token_src ? T : 0) + (pos_arr ? T : 0) + (seq_ids ? T : 0) + kv_row.size() +
                           (output_indices ? B : 0) + n_seqs + total_tbl + runs.size() + 64;
     int* host = pinned_ints(n_ints);
     int* dev = (int*)ws_get(WS_STEP, n_ints * sizeof(int));
@@ -118,6 +118,7 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
         return d;
     };
     s.d_tokens = put(tokens, T);
+    s.d_tok_src = put(token_src, T);
     s.d_pos = put(pos_arr, T);
     s.d_seq = put(seq_ids, T);
     s.d_out_idx = put(output_indices, B);

@@ -11,6 +11,7 @@ struct StepArrays {
     int write_limit;  // tokens [0, write_limit) get their K/V stored (see attention.c:159-162)
     bool table_short; // some token's logical block lies beyond its sequence's table
     int* d_tokens;    // [T]        (null when not supplied)
+    int* d_tok_src;   // [T]        (null unless supplied) -1, or the output row of the previous pass whose arg-max is the token
     int* d_pos;       // [T]
     int* d_seq;       // [T]
     int* d_out_idx;   // [B]
@@ -30,7 +31,7 @@ struct StepArrays {
 // consecutive positions.
 StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids, int T,
                       const int* output_indices, int B, BlockTable** tables, const BlockTable* single,
-                      int pos0, int block_size, int attn_ct = 0);
+                      int pos0, int block_size, int attn_ct = 0, const int* token_src = nullptr);
 
 KvPoolView pool_view(const KVCacheManager* mgr, int n_kv_heads, int head_dim);
 

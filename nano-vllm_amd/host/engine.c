@@ -32,6 +32,17 @@ __attribute__((weak)) KVCacheManager g_kv_manager;
 /* Optional: a backend that can release what load_model allocated exports this
  * (the reference has no free_model and simply leaks at exit). */
 extern void nvllm_free_model(Weights* w) __attribute__((weak));
+/* Optional: a backend that can run the forward pass in two halves (include/nvllm.h).  With greedy
+ * decoding and the arg-max hand-off nothing the scheduler decides depends on the VALUES of the
+ * sampled tokens (sequences end by length), so the driver enqueues pass n+1 -- decode rows take
+ * their token from pass n's arg-max on the GPU -- before it collects pass n: the GPU never waits
+ * for the host between steps.  Every query of sampled tokens first collects what is in flight, so
+ * the driver's observable state is that of the step-by-step loop. */
+extern long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
+                                  int num_outputs, const int* token_src, Config* p, RunState* s, Weights* w,
+                                  BlockTable** block_tables) __attribute__((weak));
+extern int nvllm_forward_collect(long ticket, int* argmax_out, int cap) __attribute__((weak));
+extern int nvllm_get_logits_mode(void) __attribute__((weak));
 
 struct NvllmEngine {
     NvllmEngineOptions opt;
@@ -55,6 +66,16 @@ struct NvllmEngine {
     BlockTable** batch_block_tables;
     int last_batch_count;
     int last_output_count;
+    /* the pass in flight (two-halves mode): which sequence each output row belongs to and where
+     * its token goes in that sequence's history (-1: nowhere) */
+    int pend_active;
+    long pend_ticket;
+    int pend_outputs;
+    int* pend_seq;
+    int* pend_hist_pos;
+    int* row_of_seq;        /* per sequence: its output row in the pass in flight, or -1 */
+    int* batch_token_src;   /* per token of the current batch: -1, or the row of the pass in flight it continues */
+    int* collected;         /* scratch for collected token ids */
     /* allocation trace */
     int* trace;
     int trace_len, trace_cap;
@@ -121,11 +142,39 @@ NvllmEngine* nvllm_engine_create(const char* model_path, int n_seqs, const Nvllm
     e->batch_sampled = (int*)malloc((size_t)n_seqs * sizeof(int));
     e->batch_block_tables = (BlockTable**)malloc((size_t)n_seqs * sizeof(BlockTable*));
     for (int i = 0; i < n_seqs; i++) e->batch_block_tables[i] = &e->seqs[i].table;
+    e->pend_seq = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->pend_hist_pos = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->row_of_seq = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->collected = (int*)malloc((size_t)n_seqs * sizeof(int));
+    e->batch_token_src = (int*)malloc((size_t)e->capacity * sizeof(int));
+    for (int i = 0; i < n_seqs; i++) e->row_of_seq[i] = -1;
     return e;
+}
+
+/* Collect the pass in flight, if any: its tokens go to the histories, become the sequences'
+ * current tokens and complete the record of the last batch. */
+static void engine_flush(NvllmEngine* e) {
+    if (!e->pend_active) return;
+    const int n = nvllm_forward_collect(e->pend_ticket, e->collected, e->n_seqs);
+    for (int k = 0; k < n && k < e->pend_outputs; k++) {
+        Sequence* s = &e->seqs[e->pend_seq[k]];
+        const int next = e->collected[k];
+        if (e->pend_hist_pos[k] >= 0) s->output_history[e->pend_hist_pos[k]] = next;
+        s->current_token = next;
+        e->batch_sampled[k] = next;
+        e->row_of_seq[e->pend_seq[k]] = -1;
+    }
+    e->pend_active = 0;
 }
 
 void nvllm_engine_destroy(NvllmEngine* e) {
     if (!e) return;
+    engine_flush(e);
+    free(e->pend_seq);
+    free(e->pend_hist_pos);
+    free(e->row_of_seq);
+    free(e->collected);
+    free(e->batch_token_src);
     for (int i = 0; i < e->n_seqs; i++) {
         free(e->seqs[i].prompt_tokens);
         free(e->seqs[i].output_history);
@@ -181,6 +230,12 @@ static void release_blocks(NvllmEngine* e, Sequence* s) {
 
 int nvllm_engine_step(NvllmEngine* e) {
     if (!e || e->finished) return 0;
+    /* two-halves mode: greedy, arg-max hand-off, and a backend that offers it */
+    const int two_halves = nvllm_forward_enqueue && nvllm_forward_collect && nvllm_get_logits_mode &&
+                           e->sampler.temperature == 0.0f && nvllm_get_logits_mode() == NVLLM_LOGITS_ARGMAX &&
+                           !getenv("NVLLM_ENGINE_STEPWISE");
+    if (!two_halves) engine_flush(e);
+    int any_src = 0;
     int all_finished = 1;
     int batch_count = 0, output_count = 0;
     int any_prefill = 0, prefill_tokens = 0, decode_tokens = 0;
@@ -233,6 +288,12 @@ int nvllm_engine_step(NvllmEngine* e) {
             e->batch_tokens[batch_count + t] = token_ptr[t];
             e->batch_pos[batch_count + t] = start_pos + t;
             e->batch_seq_ids[batch_count + t] = i;
+            e->batch_token_src[batch_count + t] = -1;
+        }
+        if (!is_prefill && e->pend_active && e->row_of_seq[i] >= 0) {
+            /* current_token is the sample of the pass in flight: the GPU supplies it */
+            e->batch_token_src[batch_count] = e->row_of_seq[i];
+            any_src = 1;
         }
         e->batch_output_indices[output_count++] = batch_count + n_tokens - 1; /* main.c:344 */
         batch_count += n_tokens;
@@ -251,8 +312,66 @@ int nvllm_engine_step(NvllmEngine* e) {
         return 1;
     }
     if (all_finished) {                                     /* main.c:364 */
+        engine_flush(e);
         e->finished = 1;
         return 0;
+    }
+
+    if (two_halves) {
+        const double t0 = now_seconds();
+        const long ticket = nvllm_forward_enqueue(e->batch_tokens, batch_count, e->batch_pos, e->batch_seq_ids,
+                                                  e->batch_output_indices, output_count, any_src ? e->batch_token_src : NULL,
+                                                  &e->config, &e->state, &e->weights, e->batch_block_tables);
+        if (ticket < 0) {
+            fprintf(stderr, "nvllm engine: the backend refused to enqueue the pass\n");
+            exit(1);
+        }
+        /* the pass before this one: its tokens also complete this batch's record */
+        if (e->pend_active) {
+            engine_flush(e);
+            for (int t = 0; t < batch_count; t++)
+                if (e->batch_token_src[t] >= 0) e->batch_tokens[t] = e->collected[e->batch_token_src[t]];
+        }
+        const double t1 = now_seconds();
+        /* bookkeeping that does not need the token values (main.c:395-409) */
+        for (int k = 0; k < output_count; k++) {
+            const int sid = e->batch_seq_ids[e->batch_output_indices[k]];
+            Sequence* s = &e->seqs[sid];
+            e->pend_seq[k] = sid;
+            e->pend_hist_pos[k] = (s->pos >= s->num_prompt_tokens && s->pos < s->seq_len) ? s->pos : -1;
+            e->row_of_seq[sid] = k;
+            e->batch_sampled[k] = -1;   /* filled when the pass is collected */
+            if (s->pos >= s->seq_len) {
+                s->active = 0;
+                s->status = SEQ_FINISHED;
+                if (e->opt.recycle_blocks) release_blocks(e, s);
+            }
+        }
+        e->pend_active = 1;
+        e->pend_ticket = ticket;
+        e->pend_outputs = output_count;
+        e->last_batch_count = batch_count;
+        e->last_output_count = output_count;
+        e->stats.steps += 1;
+        e->stats.tokens_forwarded += batch_count;
+        e->stats.prefill_tokens += prefill_tokens;
+        e->stats.decode_tokens += decode_tokens;
+        e->stats.outputs += output_count;
+        e->stats.forward_seconds += t1 - t0;
+        if (any_prefill) {
+            e->stats.prefill_step_seconds += t1 - t0;
+            e->stats.prefill_step_tokens += batch_count;
+        } else {
+            e->stats.decode_step_seconds += t1 - t0;
+            e->stats.decode_step_tokens += batch_count;
+        }
+        e->global_step++;
+        if (e->global_step > e->opt.max_steps) {            /* main.c:416-418 */
+            engine_flush(e);
+            e->finished = 1;
+            return 0;
+        }
+        return 1;
     }
 
     /* forward pass (main.c:367-369) */
@@ -321,6 +440,7 @@ const Config* nvllm_engine_config(const NvllmEngine* e) { return &e->config; }
 int nvllm_engine_seq_state(const NvllmEngine* e, int seq, int* status, int* current_token,
                            int* n_prompt, int* seq_len) {
     if (seq < 0 || seq >= e->n_seqs) return -1;
+    if (current_token) engine_flush((NvllmEngine*)e);
     const Sequence* s = &e->seqs[seq];
     if (status) *status = (int)s->status;
     if (current_token) *current_token = s->current_token;
@@ -331,6 +451,7 @@ int nvllm_engine_seq_state(const NvllmEngine* e, int seq, int* status, int* curr
 
 int nvllm_engine_history(const NvllmEngine* e, int seq, int* out, int cap) {
     if (seq < 0 || seq >= e->n_seqs) return -1;
+    engine_flush((NvllmEngine*)e);
     const Sequence* s = &e->seqs[seq];
     int filled = s->pos < s->seq_len ? s->pos : s->seq_len; /* main.c:430-431 */
     if (!s->output_history) return 0;
@@ -349,6 +470,7 @@ int nvllm_engine_block_table(const NvllmEngine* e, int seq, int* out, int cap) {
 
 int nvllm_engine_last_batch(const NvllmEngine* e, int* tokens, int* pos, int* seq_ids, int cap,
                             int* output_indices, int* sampled, int out_cap, int* num_outputs) {
+    engine_flush((NvllmEngine*)e);
     const int n = e->last_batch_count < cap ? e->last_batch_count : cap;
     if (tokens) memcpy(tokens, e->batch_tokens, (size_t)n * sizeof(int));
     if (pos) memcpy(pos, e->batch_pos, (size_t)n * sizeof(int));
