@@ -504,11 +504,25 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     // ... and already for a wide decode batch (about 128 rows) when the projection is wide enough that its
     // 128 x 128 tiles occupy most of the chip without a K split (the 7B gate/up projection at batch 128:
     // 172 tiles, 78 us against 104 us for the streaming kernel in two 64-token groups).
-    const bool wide_decode = T >= 112 && T <= 128 && cdiv(a.NB, 8) * 5 >= rt().num_cus * 3;
-    if (force_ksplit <= 0 && (T >= pf_min_t || wide_decode) && !wsp) {
+    // A projection half that wide (7B q/k/v: 96 tiles) takes it with K cut in two: 192 workgroups, and
+    // the tile's second half arrives through a 64 KiB slab (70 -> about 45 us).
+    const int tiles128 = cdiv(a.NB, 8);
+    const bool wide_decode = T >= 112 && T <= 128 && tiles128 * 5 >= rt().num_cus * 3;
+    const bool wide_decode_k2 = T >= 112 && T <= 128 && !wide_decode && tiles128 * 2 * 5 >= rt().num_cus * 3 &&
+                                tiles128 * 2 <= rt().num_cus && a.Kb >= 64 && tiles128 <= max_counters;
+    if (force_ksplit <= 0 && (T >= pf_min_t || wide_decode || wide_decode_k2) && !wsp) {
+        a.ksplit = 1;
+        a.kb_per_split = a.Kb;
+        a.slab = nullptr;
+        a.counters = g_counters;
+        if (wide_decode_k2 && T < pf_min_t) {
+            a.ksplit = 2;
+            a.kb_per_split = cdiv(a.Kb, 2);
+            a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles128 * 2 * 128 * 128 * sizeof(float));
+        }
         ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
         launch_gemm_prefill(a);
-        return 1;
+        return a.ksplit;
     }
     int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
     int nbw = GEMM_NBW;

@@ -201,6 +201,50 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& p, const f4_t (&v)[N
     }
 }
 
+// Close a K split (as in gemm.hip): every slice publishes its partial tile -- each thread its own
+// NI x NJ float4 sums, stored lane-contiguously with write-through (sc1) stores -- drains the stores,
+// and one lane takes a ticket from the tile's counter.  The workgroup that draws the last ticket
+// acquires, adds the slices in slice order (its own from the slab too, so the sum does not depend
+// on who arrived last), resets the counter and returns true: it runs the epilogue.
+template <int NI, int NJ, int THREADS>
+__device__ __forceinline__ bool pf_close_split(const GemmArgs& p, f4_t (&v)[NI][NJ], int tile_id) {
+    __shared__ unsigned s_ticket;
+    constexpr int PER_SLICE = NI * NJ * THREADS;   // float4 per slice of one tile
+    float* base = p.slab + (size_t)tile_id * p.ksplit * PER_SLICE * 4;
+    {
+        float* my = base + (size_t)blockIdx.y * PER_SLICE * 4;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, PER_SLICE * 16, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[i][j]), rs,
+                                                       ((i * NJ + j) * THREADS + (int)threadIdx.x) * 16, 0, /*sc1: write through*/ 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)p.ksplit - 1) return false;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) v[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < p.ksplit; sl++) {
+        const f4_t* src = reinterpret_cast<const f4_t*>(base + (size_t)sl * PER_SLICE * 4) + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) v[i][j] += src[(i * NJ + j) * THREADS];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 template <int FW, int KG, int EPI, typename KVT>
 __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int tiles_n, int tiles_t, int nbuf) {
     using G = PfGeom<FW, KG>;
@@ -227,6 +271,9 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
     }
     const int nb0 = (id / tiles_t) * G::FB;
     const int tb0 = (id % tiles_t) * G::TB;
+    // a K split (wide decode batches only): blockIdx.y owns K-steps [kb_lo, kb_hi)
+    const int kb_lo = blockIdx.y * p.kb_per_split;
+    const int kb_hi = min(p.Kb, kb_lo + p.kb_per_split);
 
     // ---- who copies what: tile q of a stage belongs to K-step q / TPK of the stage and is
     // weight block r (r < FB) or activation (block, plane) of r - FB, r = q % TPK; wave w
@@ -252,7 +299,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
     auto stage = [&](int s, int buf) {
 #pragma unroll
         for (int u = 0; u < G::CPW; u++) {
-            const int kb = min(s * KG + kofs[u], p.Kb - 1);
+            const int kb = min(kb_lo + s * KG + kofs[u], kb_hi - 1);
             copy_tile_to_lds(src[u] + (size_t)kb * step[u], lds_tiles + (unsigned)(buf * G::STAGE_TILES + u) * (TILE_HALVES * 2));
         }
     };
@@ -280,7 +327,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
         if (part == 0) s_rinv[tl] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss + s_rinv[tl], (float)p.e.d_in), p.e.eps)));
     }
 
-    const int n_stages = (p.Kb + KG - 1) / KG;
+    const int n_stages = (kb_hi - kb_lo + KG - 1) / KG;
     const int ahead = nbuf - 1;   // stages in flight beyond the one being multiplied
     for (int s0 = 0; s0 < ahead && s0 < n_stages; s0++) stage(s0, s0);
 
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
         __builtin_amdgcn_s_barrier();   // everybody's copies of stage s; and everybody is done reading stage s - 1
         asm volatile("" ::: "memory");
         if (s + ahead < n_stages) stage(s + ahead, wb);
-        if (KG == 1 || s * KG + kg < p.Kb) {
+        if (KG == 1 || kb_lo + s * KG + kg < kb_hi) {
             const h8_t* bw = lw + rb * (G::STAGE_HALVES / 8);
             const h8_t* ba = la + rb * (G::STAGE_HALVES / 8);
             h8_t wf[FW];
@@ -318,6 +365,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
     __syncthreads();   // the ring is free; s_rinv (written by a quarter of the threads) is visible
 
     if (KG == 1) {
+        if (p.ksplit > 1 && !pf_close_split<FW, 4, 256 * KG>(p, acc, id)) return;
         pf_epilogue<FW, 4, EPI, KVT>(p, acc, nb0 + wr * FW, wc * 4, tb0, s_rinv, lane);
     } else {
         // The two wave groups hold the sums over the even and the odd K-steps of the same
@@ -350,6 +398,7 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) fin[i][jj] = theirs[(i * 2 + jj) * 64] + acc[i][2 + jj];
         }
+        if (p.ksplit > 1 && !pf_close_split<FW, 2, 256 * KG>(p, fin, id)) return;
         pf_epilogue<FW, 2, EPI, KVT>(p, fin, nb0 + wr * FW, wc * 4 + kg * 2, tb0, s_rinv, lane);
     }
 }
@@ -364,7 +413,7 @@ void launch_one(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         allowed = shmem;
     }
-    NVLLM_LAUNCH((k_gemm_prefill<FW, KG, EPI, KVT>), dim3(tiles_n * tiles_t), dim3(256 * KG), shmem, a, tiles_n, tiles_t, nbuf);
+    NVLLM_LAUNCH((k_gemm_prefill<FW, KG, EPI, KVT>), dim3(tiles_n * tiles_t, a.ksplit), dim3(256 * KG), shmem, a, tiles_n, tiles_t, nbuf);
 }
 
 template <int FW, int KG, typename KVT>
@@ -379,16 +428,18 @@ void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
 
 }  // namespace
 
-// `a` is complete except for the K split, which this kernel does not use.
+// `a` is complete, K split included (1 unless the caller prepared slab and counters for more).
 void launch_gemm_prefill(GemmArgs a) {
-    a.ksplit = 1;
-    a.kb_per_split = a.Kb;
+    if (a.ksplit <= 1) {
+        a.ksplit = 1;
+        a.kb_per_split = a.Kb;
+    }
     const int tiles_t = cdiv(a.Tb, 8);
     const int cus = rt().num_cus;
     static const int shape_env = getenv("NVLLM_GEMM_PREFILL_SHAPE") ? atoi(getenv("NVLLM_GEMM_PREFILL_SHAPE")) : 0;   // 2: 8 waves, 3: 4 waves
     static const int ring_env = getenv("NVLLM_GEMM_PREFILL_RING") ? atoi(getenv("NVLLM_GEMM_PREFILL_RING")) : 0;
     const bool kv16 = a.e.kind == GemmEpilogue::ROPE_KV && a.e.kv_elem_bytes == 2;
-    const int wgs128 = cdiv(a.NB, 8) * tiles_t;
+    const int wgs128 = cdiv(a.NB, 8) * tiles_t * a.ksplit;
     // 128-feature tiles.  When they all fit the chip at one per CU: eight waves per
     // workgroup.  Otherwise four waves and as deep a ring as the co-resident workgroups
     // leave room for (the hardware hands a CU its next workgroup as one finishes).

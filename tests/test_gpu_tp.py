@@ -76,6 +76,34 @@ def test_7b_width_layer_with_a_single_rank(hip, oracle, tmp_models, kv_bytes):
         hip.nvllm_set_kv_elem_bytes(before)
 
 
+@pytest.mark.parametrize("tensor_parallel", [False, True])
+def test_7b_width_layer_at_batch_128(hip, oracle, tmp_models, tensor_parallel):
+    """BASELINE.json configs[4]'s batch: 128 decode rows per pass.  At that width the wide projections
+    leave the streaming kernel for 128 x 128 tiles (gate/up whole, q/k/v with K cut in two and the halves
+    met through a slab); fused epilogues (single process) and plain sums + exchange hook (one rank)."""
+    path, shape = tmp_models("tiny", seed=9, **LLAMA7B_LAYER)
+    prompts = synth.make_requests(128, 2, 3, shape.vocab_size, seed=41)
+    kw = dict(n_new=4, collect_logits=True, chunk_size=64, temperature=0.0, max_steps=50)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    assert sum(len(s_["tokens"]) == 128 for s_ in o["steps"]) >= 3
+    cb = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    if tensor_parallel:
+        assert hip.nvllm_tp_init_custom(0, 1, cb, None) == 0
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        if tensor_parallel:
+            hip.nvllm_tp_finalize()
+        hip.nvllm_set_kv_elem_bytes(before)
+    np.testing.assert_array_equal(g["trace"], o["trace"])
+    for a, b in zip(g["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+    worst = max(float(np.abs(a["logits"] - b["logits"]).max()) for a, b in zip(g["steps"], o["steps"]))
+    assert worst < LOGITS_TOL / 10, worst
+
+
 def test_rccl_communicator_of_one_rank(hip, oracle, tmp_models):
     """The RCCL plumbing end to end on the one GPU of the box: unique id, communicator,
     ncclAllReduce on the library stream between the projection and the residual kernel."""
