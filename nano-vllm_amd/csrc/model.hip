@@ -608,9 +608,8 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     float* d_logits = (float*)ws_get(WS_LOGITS, (size_t)B * V * sizeof(float));
     // the arg-max indices live in a buffer that never moves (the next pass may read them as its tokens)
     int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(p->max_seq_len + 64) * sizeof(int));
-    if (st.d_tok_src) launch_patch_tokens(st.d_tokens, st.d_tok_src, d_argmax, T);
-
     if (m->f32) {   // fp32 weights: the reference's operator sequence
+        if (st.d_tok_src) launch_patch_tokens(st.d_tokens, st.d_tok_src, d_argmax, T);
         forward_f32(st, T, B, p, s, w, pool, rope, d_logits);
         launch_argmax(d_argmax, d_logits, B, V);
         g_tp_full_valid = true;
@@ -618,7 +617,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     }
 
     // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
-    launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D);
+    launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D, st.d_tok_src, d_argmax);
 
     for (int l = 0; l < p->n_layers; l++) {
         const LayerPriv& lp = m->layers[l];

@@ -282,14 +282,16 @@ void launch_paged_attention(const AttnArgs& a);
 int attn_tokens_per_item(int H, int KVH);
 
 // x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 32j..32j+31
+// tok_src / prev (optional): where tok_src[t] >= 0 the token id is prev[tok_src[t]] instead of tokens[t]
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
-                           const float* gain, int T, int D);
+                           const float* gain, int T, int D, const int* tok_src = nullptr, const int* prev = nullptr);
 // x[t,:] += y[t,:]; a16 = x * gain in hi/lo tiles; ss as above (the tail of a residual projection
 // whose sums were completed outside the projection kernel)
 void launch_resid_prescale(float* x, const float* y, __half* a16, float* ss, const float* gain, int T, int D);
 // rows idx[r] of an a16 activation (and of its ss table) compacted to rows r = 0..B-1
 void launch_gather_a16(__half* dst, float* dst_ss, const __half* src, const float* src_ss, const int* idx,
                        int B, int K, int ss_tiles);
+void launch_copy_ints(int* dst, const int* host_src, size_t n);   // host_src: page-locked, 16-byte aligned, padded to 4 ints
 void launch_patch_tokens(int* tokens, const int* src, const int* prev, int T);
 void launch_gather_rows_f32(float* dst, const float* src, const int* idx, int B, int D);
 void launch_swiglu(float* out, const float* g, const float* u, long n);

@@ -143,7 +143,11 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
     }
     o = (o + 3) & ~(size_t)3;  // int4 alignment
     s.d_runs = runs.empty() ? nullptr : put(runs.data(), runs.size());
-    if (o > 0) HIP_CHECK(hipMemcpyAsync(dev, host, o * sizeof(int), hipMemcpyHostToDevice, rt().stream));
+    if (o > 0) {
+        static const int by_kernel = getenv("NVLLM_STAGE_COPY") ? atoi(getenv("NVLLM_STAGE_COPY")) == 0 : 1;
+        if (by_kernel && o <= (1u << 16)) launch_copy_ints(dev, host, o);   // small: a kernel reads the pinned region itself
+        else HIP_CHECK(hipMemcpyAsync(dev, host, o * sizeof(int), hipMemcpyHostToDevice, rt().stream));
+    }
     return s;
 }
 

@@ -105,3 +105,20 @@ def test_forward_in_two_halves_through_the_c_abi(hip, tmp_models):
     finally:
         hip.nvllm_set_logits_mode(0)
     assert hip.nvllm_forward_enqueue(None, 1, None, None, None, 0, None, None, None, None, None) == -1   # wrong hand-off mode
+
+
+def test_two_halves_mode_on_an_fp32_resident_model(hip, oracle, tmp_models):
+    """The fp32 operator path takes its chained tokens through the patch kernel."""
+    path, shape = tmp_models("tiny", seed=14, dtype="f32", shared=True, rope_tail=True, exact16=False)
+    prompts = synth.make_requests(4, 3, 30, shape.vocab_size, seed=61)
+    n_new, arrivals = [9, 6, 12, 7], [0, 0, 2, 5]
+    opts = dict(chunk_size=16, temperature=0.0, max_steps=200)
+    want = util.run_engine(oracle, path, prompts, n_new, arrivals=arrivals, **opts)
+    hip.nvllm_set_logits_mode(1)
+    try:
+        got = _run_blind(hip, path, prompts, n_new, arrivals, **opts)
+    finally:
+        hip.nvllm_set_logits_mode(0)
+    np.testing.assert_array_equal(got["trace"], want["trace"])
+    for a, b in zip(got["histories"], want["histories"]):
+        np.testing.assert_array_equal(a, b)
