@@ -129,3 +129,45 @@ def test_long_context_4k_forward_pass(hip, oracle, tmp_path_factory):
             hip.nvllm_set_kv_elem_bytes(before)
         _compare(g, o, LOGITS_TOL / 10 if kv_bytes == 2 else 2e-4)
         _kv_close(g, o, fp16_pool=kv_bytes == 2)
+
+
+def test_full_size_run_is_reproducible_and_mode_independent(hip, tinyllama):
+    """At the benchmark's full width and length, where the oracle is out of reach: 64 sequences, 128-token
+    prompts in 512-token passes, 256 greedy steps.  The kernels sum in a fixed order, so two runs must give
+    the same tokens, and the driver's two-halves mode (tokens chained on the GPU) the same as its
+    step-by-step loop; allocation is the plain 0, 1, 2, ... of the reference's stack."""
+    import os
+    from nvllm_amd import capi
+    path, shape = tinyllama
+    prompts = synth.make_requests(64, 128, 128, shape.vocab_size, seed=31)
+
+    def run(stepwise):
+        if stepwise:
+            os.environ["NVLLM_ENGINE_STEPWISE"] = "1"
+        try:
+            e = capi.Engine(hip, path, 64, chunk_size=512, temperature=0.0, max_seq_len=2048, max_steps=1 << 20)
+            for i, p in enumerate(prompts):
+                e.set_request(i, p, 256, 0)
+            steps = e.run_all()
+            out = ([e.history(i) for i in range(64)], e.alloc_trace(), steps)
+            e.close()
+            return out
+        finally:
+            os.environ.pop("NVLLM_ENGINE_STEPWISE", None)
+
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    hip.nvllm_set_logits_mode(1)
+    try:
+        a, b, c = run(False), run(False), run(True)
+    finally:
+        hip.nvllm_set_logits_mode(0)
+        hip.nvllm_set_kv_elem_bytes(before)
+    assert a[2] == b[2] == c[2] and a[2] >= 256
+    np.testing.assert_array_equal(a[1][:, 2], np.arange(a[1].shape[0]))
+    for other in (b, c):
+        np.testing.assert_array_equal(a[1], other[1])
+        for x, y in zip(a[0], other[0]):
+            np.testing.assert_array_equal(x, y)
+    assert all(len(h) == 128 + 256 for h in a[0])
+    assert len({tuple(h[128:].tolist()) for h in a[0]}) > 32        # the sequences really generate different text
