@@ -28,7 +28,7 @@ struct GemmArgs {
 #endif
 };
 
-// In-kernel timeline for diagnostic builds (tools/micro/proj_bench.hip): wave 0 of every workgroup
+// In-kernel timeline for diagnostic builds (tools/gemm_stamps.py): wave 0 of every workgroup
 // records the 100 MHz constant-rate clock once the value `dep` exists.  Compiled out otherwise.
 #ifdef NVLLM_STAMPS
 #define NVLLM_STAMP(k, dep)                                                                                   \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (here, after tools/gpu_evidence.sh <tag> ran on the GPU box and its output was merged back):
 #   tools/collect_profiles.sh <tag> <round>     e.g.  tools/collect_profiles.sh r02a r02
-# Copies the summaries that the bench line and DESIGN.md cite from gpurun_out/ (scratch) to profiles/ (tracked).
+# Copies the summaries that the bench line refers to from gpurun_out/ (scratch) to profiles/ (tracked).
 tag=$1; rnd=$2
 set -e
 cp gpurun_out/${tag}_kernels.txt profiles/${rnd}_decode_kernels.txt
