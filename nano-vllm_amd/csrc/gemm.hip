@@ -515,11 +515,14 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         a.kb_per_split = a.Kb;
         a.slab = nullptr;
         a.counters = g_counters;
-        if (wide_decode_k2 && T < pf_min_t) {
-            a.ksplit = 2;
-            a.kb_per_split = cdiv(a.Kb, 2);
-            a.slab = (float*)ws_get(WS_SLAB, (size_t)tiles128 * 2 * 128 * 128 * sizeof(float));
+        if (wide_decode_k2 && T < pf_min_t) a.ksplit = 2;   // every tile's K in two (slab: the launcher's)
+#ifdef NVLLM_STAMPS
+        a.stamps = nullptr;
+        if (g_gemm_stamps && g_stamp_cap > 0) {
+            a.stamps = g_gemm_stamps + (size_t)(g_stamp_next % g_stamp_cap) * STAMP_WGS * 8;
+            g_stamp_next++;
         }
+#endif
         ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
         launch_gemm_prefill(a);
         return a.ksplit;

@@ -36,6 +36,8 @@
 // features of one token, the gate and up rows of a hidden unit sit in the same lane, and
 // the per-token sums of squares need two cross-lane adds -- no LDS pass.
 #include "gemm_common.h"
+#include <type_traits>
+#include <algorithm>
 
 namespace nvllm {
 
@@ -43,17 +45,21 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-// FW = 16-row weight blocks per wave (4 or 8), KG = groups of four waves that split the K-steps
-template <int FW, int KG>
+// FW = 16-row weight blocks per wave (4 or 8), KG = wave groups that split the K-steps, WR = rows of
+// the wave grid (WR x 2 waves per group: 2 -> 128-feature tiles, 4 -> 256-feature tiles), TW = 16-token
+// blocks per wave (4, 3 or 2: the tile's height is chosen per launch so that its rounds of workgroups fill)
+template <int FW, int KG, int WR = 2, int TW = 4>
 struct PfGeom {
-    static constexpr int FB = 2 * FW;                  // weight blocks per workgroup tile
-    static constexpr int TB = 8;                       // 16-token blocks per workgroup tile (128 tokens)
+    static constexpr int FB = WR * FW;                 // weight blocks per workgroup tile
+    static constexpr int TB = 2 * TW;                  // 16-token blocks per workgroup tile: two wave columns of TW (128, 96 or 64 tokens)
     static constexpr int TPK = FB + 2 * TB;            // 1-KiB tiles per K-step: weights, then (hi, lo) per token block
     static constexpr int STAGE_TILES = KG * TPK;       // a stage = KG consecutive K-steps = what one barrier publishes
     static constexpr int STAGE_HALVES = STAGE_TILES * TILE_HALVES;
-    static constexpr int WAVES = 4 * KG;
-    static constexpr int CPW = STAGE_TILES / WAVES;    // copies per wave per stage (6 or 8)
-    static constexpr int RINV_HALVES = 2 * TB * 16;    // 128 floats in front of the ring
+    static constexpr int WAVES = 2 * WR * KG;
+    static constexpr int CPW = STAGE_TILES / WAVES;    // copies per wave per stage (4, 6 or 8)
+    static_assert(STAGE_TILES % WAVES == 0, "every wave copies the same number of tiles");
+    static_assert(TW == 4 || KG == 1, "the two-group form exchanges halves of four token blocks");
+    static constexpr int RINV_HALVES = 256;            // 128 floats in front of the ring (1/rms of up to 128 tokens)
 };
 
 // One wave copies one 1-KiB tile global -> LDS without passing through registers: lane l's
@@ -69,27 +75,27 @@ __device__ __forceinline__ void copy_tile_to_lds(const __half* lane_src, unsigne
                  : "memory");
 }
 
+// The same copy for the steady state of the K loop: M0 is written and left (nothing else in
+// this kernel reads it: the compiler sets M0 itself right before any use of its own), the LDS address is a wave-uniform
+// base plus a constant.
+template <int OFS>
+__device__ __forceinline__ void copy_tile_to_lds_at(const __half* lane_src, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(lane_src), "s"(lds_base), "n"(OFS)
+                 : "memory");
+}
+
 // wait until at most `stages` stages of this wave's copies (CPW each) are still in flight;
 // s_waitcnt takes an immediate
 template <int CPW>
 __device__ __forceinline__ void wait_copies_but(int stages) {
-    static_assert(CPW == 6 || CPW == 8, "immediates below");
-    if (CPW == 6) {
-        switch (stages) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        }
-    } else {
-        switch (stages) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-        }
+    switch (stages) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPW) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CPW) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CPW) : "memory"); break;
     }
 }
 
@@ -207,12 +213,12 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& p, const f4_t (&v)[N
 // acquires, adds the slices in slice order (its own from the slab too, so the sum does not depend
 // on who arrived last), resets the counter and returns true: it runs the epilogue.
 template <int NI, int NJ, int THREADS>
-__device__ __forceinline__ bool pf_close_split(const GemmArgs& p, f4_t (&v)[NI][NJ], int tile_id) {
+__device__ __forceinline__ bool pf_close_split(const GemmArgs& p, f4_t (&v)[NI][NJ], int tile_id, int slice) {
     __shared__ unsigned s_ticket;
     constexpr int PER_SLICE = NI * NJ * THREADS;   // float4 per slice of one tile
     float* base = p.slab + (size_t)tile_id * p.ksplit * PER_SLICE * 4;
     {
-        float* my = base + (size_t)blockIdx.y * PER_SLICE * 4;
+        float* my = base + (size_t)slice * PER_SLICE * 4;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, PER_SLICE * 16, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NI; i++)
@@ -227,27 +233,37 @@ __device__ __forceinline__ bool pf_close_split(const GemmArgs& p, f4_t (&v)[NI][
         s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (unsigned)p.ksplit - 1) return false;
+#ifdef NVLLM_PF_CLOSE_FENCE
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
     __syncthreads();
+#endif
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) v[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
     for (int sl = 0; sl < p.ksplit; sl++) {
-        const f4_t* src = reinterpret_cast<const f4_t*>(base + (size_t)sl * PER_SLICE * 4) + threadIdx.x;
+        // coherent (sc1) loads: they do not hit lines this XCD's L2 may hold from an earlier
+        // launch's slab, and need no cache invalidate -- which would also drop the weights and
+        // activations the other workgroups behind this L2 are sharing
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)sl * PER_SLICE * 4, 0, PER_SLICE * 16, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
-            for (int j = 0; j < NJ; j++) v[i][j] += src[(i * NJ + j) * THREADS];
+            for (int j = 0; j < NJ; j++)
+                v[i][j] += __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * NJ + j) * THREADS + (int)threadIdx.x) * 16, 0, /*sc1*/ 16));
     }
     if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
-template <int FW, int KG, int EPI, typename KVT>
-__global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int tiles_n, int tiles_t, int nbuf) {
-    using G = PfGeom<FW, KG>;
+template <int FW, int KG, int EPI, typename KVT, int WR = 2, int TW = 4>
+__global__ __launch_bounds__(128 * WR * KG, WR == 4 ? 4 : 2) void k_gemm_prefill(GemmArgs p, int tiles_n, int tiles_t, int nbuf, int split_from) {
+    using G = PfGeom<FW, KG, WR, TW>;
+#ifdef NVLLM_PF_ABLATE
+    const int ablate = nbuf >> 8;   // diagnostic build: 1 no in-loop copies, 2 no multiplies, 4 no LDS reads, 8 no barrier, 16 no epilogue
+    nbuf &= 255;
+#endif
     // all LDS is one object: 128 floats of 1/rms, then the ring [nbuf][STAGE_TILES][512 halves]
     extern __shared__ __attribute__((aligned(16))) __half lds_all[];
     float* s_rinv = reinterpret_cast<float*>(lds_all);
@@ -255,25 +271,37 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kg = wave >> 2;                         // which K-steps of a stage this wave multiplies
-    const int wr = (wave >> 1) & 1, wc = wave & 1;    // its FW*16 features x 64 tokens inside the tile
+    NVLLM_STAMP(0, lane);
+    const int kg = wave / (2 * WR);                   // which K-steps of a stage this wave multiplies
+    const int wr = (wave >> 1) % WR, wc = wave & 1;   // its FW*16 features x 64 tokens inside the tile
 
     // Workgroups are dealt round-robin to the 8 XCDs.  Give every XCD a contiguous range
     // of the (feature tile, token tile) sequence, token tiles fastest: the workgroups that
     // run together behind one L2 then share a few weight tiles and all walk the same
     // activations.
+    // Tiles [0, split_from) are one workgroup each; the tiles after them (the launch's last,
+    // partly filled round of workgroup slots -- or every tile of a launch too small to fill
+    // the chip) are cut into p.ksplit slices of K, one workgroup per slice, closed below.
     const int total = tiles_n * tiles_t;
-    int id = blockIdx.x;
-    {
-        const int xcd = id & 7, slot = id >> 3;
-        const int q = total >> 3, r = total & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    auto deal = [](int i, int n) {   // position i of n dealt to 8 XCDs -> place in the XCD-contiguous order
+        const int xcd = i & 7, slot = i >> 3;
+        const int q = n >> 3, r = n & 7;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    };
+    int id, slice = 0;
+    const bool split = (int)blockIdx.x >= split_from;
+    if (!split) {
+        id = deal(blockIdx.x, split_from);
+    } else {
+        const int j = deal(blockIdx.x - split_from, (total - split_from) * p.ksplit);
+        id = split_from + j / p.ksplit;
+        slice = j % p.ksplit;
     }
     const int nb0 = (id / tiles_t) * G::FB;
     const int tb0 = (id % tiles_t) * G::TB;
-    // a K split (wide decode batches only): blockIdx.y owns K-steps [kb_lo, kb_hi)
-    const int kb_lo = blockIdx.y * p.kb_per_split;
-    const int kb_hi = min(p.Kb, kb_lo + p.kb_per_split);
+    // K-steps [kb_lo, kb_hi) of this workgroup
+    const int kb_lo = split ? slice * p.kb_per_split : 0;
+    const int kb_hi = split ? min(p.Kb, kb_lo + p.kb_per_split) : p.Kb;
 
     // ---- who copies what: tile q of a stage belongs to K-step q / TPK of the stage and is
     // weight block r (r < FB) or activation (block, plane) of r - FB, r = q % TPK; wave w
@@ -300,15 +328,16 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
 #pragma unroll
         for (int u = 0; u < G::CPW; u++) {
             const int kb = min(kb_lo + s * KG + kofs[u], kb_hi - 1);
-            copy_tile_to_lds(src[u] + (size_t)kb * step[u], lds_tiles + (unsigned)(buf * G::STAGE_TILES + u) * (TILE_HALVES * 2));
+            copy_tile_to_lds(src[u] + (size_t)kb * step[u],
+                             __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)(buf * G::STAGE_TILES + u) * (TILE_HALVES * 2)));
         }
     };
 
-    f4_t acc[FW][4];
+    f4_t acc[FW][TW];
 #pragma unroll
     for (int i = 0; i < FW; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TW; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     // 1/rms of the tile's tokens from the producer's sums of squares (two threads per token);
     // done before the first copy is issued, so that its barrier does not wait for copies
@@ -330,50 +359,160 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
     const int n_stages = (kb_hi - kb_lo + KG - 1) / KG;
     const int ahead = nbuf - 1;   // stages in flight beyond the one being multiplied
     for (int s0 = 0; s0 < ahead && s0 < n_stages; s0++) stage(s0, s0);
+    NVLLM_STAMP(1, lane);
+
+    // Steady state: stage s + ahead is a whole stage inside [kb_lo, kb_hi), so its copies need
+    // no clamp -- every copy keeps a running source pointer and adds a constant per stage
+    // (four instructions per copy instead of the dozen of the general form; at one
+    // instruction per wave every four to five cycles that is what the loop's time is made of).
+    const __half* cp[G::CPW];
+    long adv[G::CPW];
+#pragma unroll
+    for (int u = 0; u < G::CPW; u++) {
+        cp[u] = src[u] + (size_t)(kb_lo + ahead * KG + kofs[u]) * step[u];
+        adv[u] = (long)KG * step[u];
+    }
+    auto stage_steady = [&](int buf) {
+        // (readfirstlane: a scalar register even where the compiler could fold the sum into a literal)
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)buf * (unsigned)(G::STAGE_TILES * TILE_HALVES * 2));
+#pragma unroll
+        for (int u = 0; u < G::CPW; u++) {
+            if (u == 0) copy_tile_to_lds_at<0>(cp[u], base);
+            if (u == 1) copy_tile_to_lds_at<1 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 2) copy_tile_to_lds_at<2 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 3) copy_tile_to_lds_at<3 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 4) copy_tile_to_lds_at<4 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 5) copy_tile_to_lds_at<5 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 6) copy_tile_to_lds_at<6 * TILE_HALVES * 2>(cp[u], base);
+            if (u == 7) copy_tile_to_lds_at<7 * TILE_HALVES * 2>(cp[u], base);
+            cp[u] += adv[u];
+        }
+    };
 
     const h8_t* lw = reinterpret_cast<const h8_t*>(lds) + (kg * G::TPK + wr * FW) * 64 + lane;             // weight tiles of this wave
-    const h8_t* la = reinterpret_cast<const h8_t*>(lds) + (kg * G::TPK + G::FB + wc * 4 * 2) * 64 + lane;  // its activation tiles
+    const h8_t* la = reinterpret_cast<const h8_t*>(lds) + (kg * G::TPK + G::FB + wc * TW * 2) * 64 + lane;  // its activation tiles
     int rb = 0;               // buffer of stage s
     int wb = ahead % nbuf;    // buffer of stage s + ahead (= the one read at stage s - 1)
-    for (int s = 0; s < n_stages; s++) {
-        // this wave's copies of stage s have landed; the stages issued after it may still fly
-        wait_copies_but<G::CPW>(min(ahead - 1, n_stages - 1 - s));
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // everybody's copies of stage s; and everybody is done reading stage s - 1
-        asm volatile("" ::: "memory");
-        if (s + ahead < n_stages) stage(s + ahead, wb);
-        if (KG == 1 || kb_lo + s * KG + kg < kb_hi) {
-            const h8_t* bw = lw + rb * (G::STAGE_HALVES / 8);
-            const h8_t* ba = la + rb * (G::STAGE_HALVES / 8);
-            h8_t wf[FW];
+
+    // the multiplies of one stage out of buffer rb
+    auto multiply = [&]() {
+        const h8_t* bw = lw + rb * (G::STAGE_HALVES / 8);
+        const h8_t* ba = la + rb * (G::STAGE_HALVES / 8);
+        // every fragment of the K-step is requested before the first multiply (the LDS returns
+        // them in order, so each group of multiplies waits only for its own two): left to
+        // itself the scheduler re-uses two fragment registers and exposes an LDS round trip
+        // in front of every eight multiplies
+        h8_t wf[FW], af[2 * TW];
+#ifdef NVLLM_PF_ABLATE
+        if (ablate & 4) {
+#pragma unroll
+            for (int i = 0; i < FW; i++) asm volatile("" : "=v"(wf[i]));
+#pragma unroll
+            for (int j = 0; j < 2 * TW; j++) asm volatile("" : "=v"(af[j]));
+        } else
+#endif
+        {
 #pragma unroll
             for (int i = 0; i < FW; i++) wf[i] = bw[i * 64];
-            __builtin_amdgcn_s_setprio(1);   // a wave that is multiplying keeps the issue slot over one that is copying
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const h8_t ah = ba[(2 * j) * 64], al = ba[(2 * j + 1) * 64];
-#pragma unroll
-                for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], ah, acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], al, acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
+            for (int j = 0; j < 2 * TW; j++) af[j] = ba[j * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NVLLM_PF_ABLATE
+        if (ablate & 2) {
+#pragma unroll
+            for (int i = 0; i < FW; i++) asm volatile("" ::"v"(wf[i]));
+#pragma unroll
+            for (int j = 0; j < 2 * TW; j++) asm volatile("" ::"v"(af[j]));
+            return;
+        }
+#endif
+        __builtin_amdgcn_s_setprio(1);   // a wave that is multiplying keeps the issue slot over one that is copying
+#pragma unroll
+        for (int j = 0; j < TW; j++) {
+#pragma unroll
+            for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[2 * j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < FW; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], af[2 * j + 1], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    int s = 0;
+    // ---- steady state: stages s .. s + ahead - 1 in flight at the wait, all whole.  One copy
+    // of the loop per ring depth, so that the wait is a single instruction with its immediate.
+    const int n_steady = n_stages - ahead - 1;   // stage s + ahead must not be the last one (which may be ragged)
+    auto steady = [&](auto in_flight) {
+        constexpr int LEAVE = decltype(in_flight)::value * G::CPW;
+        for (; s < n_steady; s++) {
+            // this wave's copies of stage s have landed; the stages issued after it may still fly
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
+#ifdef NVLLM_PF_ABLATE
+            if (!(ablate & 8))
+#endif
+            __builtin_amdgcn_s_barrier();   // everybody's copies of stage s; and everybody is done reading stage s - 1
+            asm volatile("" ::: "memory");
+#ifdef NVLLM_PF_ABLATE
+            if (!(ablate & 1))
+#endif
+            stage_steady(wb);
+            if (s == 0) NVLLM_STAMP(2, lane);
+            multiply();
+            rb = rb + 1 == nbuf ? 0 : rb + 1;
+            wb = wb + 1 == nbuf ? 0 : wb + 1;
+        }
+    };
+    switch (ahead) {
+        case 1: steady(std::integral_constant<int, 0>{}); break;
+        case 2: steady(std::integral_constant<int, 1>{}); break;
+        case 3: steady(std::integral_constant<int, 2>{}); break;
+        case 4: steady(std::integral_constant<int, 3>{}); break;
+        default: break;   // deeper rings run in the general loop below
+    }
+    // ---- the last stages: clamped copies, waits that count down
+    for (; s < n_stages; s++) {
+        wait_copies_but<G::CPW>(min(ahead - 1, n_stages - 1 - s));
+        asm volatile("" ::: "memory");
+#ifdef NVLLM_PF_ABLATE
+        if (!(ablate & 8))
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef NVLLM_PF_ABLATE
+        if (!(ablate & 1))
+#endif
+        if (s + ahead < n_stages) stage(s + ahead, wb);
+        if (s == 0) NVLLM_STAMP(2, lane);
+        if (KG == 1 || kb_lo + s * KG + kg < kb_hi) multiply();
         rb = rb + 1 == nbuf ? 0 : rb + 1;
         wb = wb + 1 == nbuf ? 0 : wb + 1;
     }
+    NVLLM_STAMP(3, acc[FW - 1][TW - 1][0]);
     __syncthreads();   // the ring is free; s_rinv (written by a quarter of the threads) is visible
+    NVLLM_STAMP(4, lane);
 
     if (KG == 1) {
-        if (p.ksplit > 1 && !pf_close_split<FW, 4, 256 * KG>(p, acc, id)) return;
-        pf_epilogue<FW, 4, EPI, KVT>(p, acc, nb0 + wr * FW, wc * 4, tb0, s_rinv, lane);
+        if (split && !pf_close_split<FW, TW, 128 * WR * KG>(p, acc, id - split_from, slice)) {
+            NVLLM_STAMP(7, lane);
+            return;
+        }
+        NVLLM_STAMP(7, acc[FW - 1][TW - 1][0]);
+#ifdef NVLLM_PF_ABLATE
+        if ((ablate & 16) && acc[0][0][0] != 123.25f) return;   // 16: no epilogue (the test keeps the sums alive)
+#endif
+        pf_epilogue<FW, TW, EPI, KVT>(p, acc, nb0 + wr * FW, wc * TW, tb0, s_rinv, lane);
+        NVLLM_STAMP(5, lane);
+#ifdef NVLLM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores issued so far have left the CU
+#endif
+        NVLLM_STAMP(6, lane);
     } else {
         // The two wave groups hold the sums over the even and the odd K-steps of the same
         // outputs.  Each wave keeps two of its four token blocks and hands the other two to
         // its partner (same wr, wc in the other group) through the ring's memory.
         f4_t* xch = reinterpret_cast<f4_t*>(lds);                  // [wave][FW][2][64]
         f4_t* mine = xch + (size_t)wave * (FW * 2 * 64) + lane;
-        const f4_t* theirs = xch + (size_t)(wave ^ 4) * (FW * 2 * 64) + lane;
+        const f4_t* theirs = xch + (size_t)(wave ^ (2 * WR)) * (FW * 2 * 64) + lane;
         f4_t fin[FW][2];
         if (kg == 0) {
 #pragma unroll
@@ -398,66 +537,118 @@ __global__ __launch_bounds__(256 * KG, 2) void k_gemm_prefill(GemmArgs p, int ti
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) fin[i][jj] = theirs[(i * 2 + jj) * 64] + acc[i][2 + jj];
         }
-        if (p.ksplit > 1 && !pf_close_split<FW, 2, 256 * KG>(p, fin, id)) return;
+        if (split && !pf_close_split<FW, 2, 128 * WR * KG>(p, fin, id - split_from, slice)) return;
         pf_epilogue<FW, 2, EPI, KVT>(p, fin, nb0 + wr * FW, wc * 4 + kg * 2, tb0, s_rinv, lane);
     }
 }
 
-template <int FW, int KG, int EPI, typename KVT>
-void launch_one(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
-    using G = PfGeom<FW, KG>;
-    const size_t shmem = (size_t)(G::RINV_HALVES + nbuf * G::STAGE_HALVES) * sizeof(__half);
+template <int FW, int KG, int EPI, typename KVT, int TW>
+void launch_one(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf, int split_from) {
+    using G = PfGeom<FW, KG, 2, TW>;
+    const size_t shmem = (size_t)(G::RINV_HALVES + (nbuf & 255) * G::STAGE_HALVES) * sizeof(__half);   // (a diagnostic build keeps flags above bit 8)
     static size_t allowed = 0;   // per instantiation: the largest dynamic LDS size enabled so far
     if (shmem > allowed) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_prefill<FW, KG, EPI, KVT>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_prefill<FW, KG, EPI, KVT, 2, TW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         allowed = shmem;
     }
-    NVLLM_LAUNCH((k_gemm_prefill<FW, KG, EPI, KVT>), dim3(tiles_n * tiles_t, a.ksplit), dim3(256 * KG), shmem, a, tiles_n, tiles_t, nbuf);
+    NVLLM_LAUNCH((k_gemm_prefill<FW, KG, EPI, KVT, 2, TW>), dim3(split_from + (tiles_n * tiles_t - split_from) * a.ksplit), dim3(256 * KG), shmem, a,
+                 tiles_n, tiles_t, nbuf, split_from);
 }
 
-template <int FW, int KG, typename KVT>
-void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf) {
+template <int FW, int KG, typename KVT, int TW = 4>
+void launch_pf(const GemmArgs& a, int tiles_n, int tiles_t, int nbuf, int split_from) {
     switch (a.e.kind) {
-        case GemmEpilogue::F32: launch_one<FW, KG, GemmEpilogue::F32, KVT>(a, tiles_n, tiles_t, nbuf); break;
-        case GemmEpilogue::SWIGLU_A16: launch_one<FW, KG, GemmEpilogue::SWIGLU_A16, KVT>(a, tiles_n, tiles_t, nbuf); break;
-        case GemmEpilogue::RESID_A16: launch_one<FW, KG, GemmEpilogue::RESID_A16, KVT>(a, tiles_n, tiles_t, nbuf); break;
-        default: launch_one<FW, KG, GemmEpilogue::ROPE_KV, KVT>(a, tiles_n, tiles_t, nbuf); break;
+        case GemmEpilogue::F32: launch_one<FW, KG, GemmEpilogue::F32, KVT, TW>(a, tiles_n, tiles_t, nbuf, split_from); break;
+        case GemmEpilogue::SWIGLU_A16: launch_one<FW, KG, GemmEpilogue::SWIGLU_A16, KVT, TW>(a, tiles_n, tiles_t, nbuf, split_from); break;
+        case GemmEpilogue::RESID_A16: launch_one<FW, KG, GemmEpilogue::RESID_A16, KVT, TW>(a, tiles_n, tiles_t, nbuf, split_from); break;
+        default: launch_one<FW, KG, GemmEpilogue::ROPE_KV, KVT, TW>(a, tiles_n, tiles_t, nbuf, split_from); break;
     }
 }
 
 }  // namespace
 
-// `a` is complete, K split included (1 unless the caller prepared slab and counters for more).
+// `a` is complete but for the K split: a.ksplit > 1 asks for every tile to be cut that many ways
+// (wide decode batches; slab and counters are the library's own), otherwise none is.
 void launch_gemm_prefill(GemmArgs a) {
-    if (a.ksplit <= 1) {
-        a.ksplit = 1;
-        a.kb_per_split = a.Kb;
-    }
-    const int tiles_t = cdiv(a.Tb, 8);
     const int cus = rt().num_cus;
     static const int shape_env = getenv("NVLLM_GEMM_PREFILL_SHAPE") ? atoi(getenv("NVLLM_GEMM_PREFILL_SHAPE")) : 0;   // 2: 8 waves, 3: 4 waves
     static const int ring_env = getenv("NVLLM_GEMM_PREFILL_RING") ? atoi(getenv("NVLLM_GEMM_PREFILL_RING")) : 0;
+    static const int ksplit_env = getenv("NVLLM_GEMM_PREFILL_KSPLIT") ? atoi(getenv("NVLLM_GEMM_PREFILL_KSPLIT")) : 0;   // cut every tile this many ways
+    static const int tw_env = getenv("NVLLM_GEMM_PREFILL_TW") ? atoi(getenv("NVLLM_GEMM_PREFILL_TW")) : 0;               // token blocks per wave: 4, 3, 2
+#ifdef NVLLM_PF_ABLATE
+    static const int ablate_env = getenv("NVLLM_PF_ABLATE") ? atoi(getenv("NVLLM_PF_ABLATE")) << 8 : 0;
+#else
+    constexpr int ablate_env = 0;
+#endif
     const bool kv16 = a.e.kind == GemmEpilogue::ROPE_KV && a.e.kv_elem_bytes == 2;
-    const int wgs128 = cdiv(a.NB, 8) * tiles_t * a.ksplit;
-    // 128-feature tiles.  When they all fit the chip at one per CU: eight waves per
-    // workgroup.  Otherwise four waves and as deep a ring as the co-resident workgroups
-    // leave room for (the hardware hands a CU its next workgroup as one finishes).
-    int shape = wgs128 <= cus ? 2 : 3;
-    if (shape_env) shape = shape_env;
-    if (shape == 2) {          // 48 KiB per stage (two K-steps); a ring of three fills the LDS
-        const int tiles_n = cdiv(a.NB, 8);
-        int nbuf = 3;
+    int want_split = a.ksplit > 1 ? a.ksplit : 1;
+    if (ksplit_env > 1) want_split = ksplit_env;
+    const int tiles_n = cdiv(a.NB, 8);
+    // 128-feature tiles, 128, 96 or 64 tokens high.  A launch runs in rounds of co-resident
+    // workgroups (three per CU with two ring buffers) and a partly filled last round costs
+    // nearly a full one, so the height is the one whose rounds waste least: 128 tokens unless
+    // 96 needs fewer round-heights (TinyLlama's gate/up at 1,591 tokens: 1,144 tiles = 1.5 rounds
+    // against 1,496 = 1.95 rounds of 3/4 the height, 150 -> 147 us; a projection half as wide
+    // 88 -> 74 us).  Projections whose 128-token tiles would not even give every CU one
+    // workgroup (wo, w_down: 208) take 64-token tiles, two workgroups per CU with three buffers
+    // (35 -> 32 and 80 -> 77 us against the eight-wave form, which wide decode batches keep:
+    // there every weight tile must still be read only once).
+    const int tiles4 = tiles_n * cdiv(a.Tb, 8);
+    const bool wide_decode = a.Tb <= 8 || want_split > 1;
+    int shape = wide_decode && tiles4 * want_split <= cus ? 2 : 3;
+    if (shape_env == 2 || shape_env == 3) shape = shape_env;
+    int tw = 4;
+    if (shape == 3 && !wide_decode) {
+        if (tiles4 <= cus) {
+            tw = 2;
+        } else {
+            const int slots = 3 * cus;
+            const int tiles3 = tiles_n * cdiv(a.Tb, 6);
+            if (cdiv(tiles3, slots) * 3 < cdiv(tiles4, slots) * 4) tw = 3;
+        }
+    }
+    if (shape == 3 && tw_env >= 2 && tw_env <= 4) tw = tw_env;
+    const int tiles_t = cdiv(a.Tb, 2 * tw);
+    const int total = tiles_n * tiles_t;
+    int nbuf;
+    if (shape == 2) {   // 48 KiB per stage (two K-steps); a ring of three fills the LDS
+        nbuf = 3;
         if (ring_env >= 2 && ring_env <= 3) nbuf = ring_env;
-        if (kv16) launch_pf<4, 2, __half>(a, tiles_n, tiles_t, nbuf);
-        else launch_pf<4, 2, float>(a, tiles_n, tiles_t, nbuf);
-    } else {                   // 24 KiB per stage
-        const int tiles_n = cdiv(a.NB, 8);
-        const int per_cu = cdiv(wgs128, cus);
-        int nbuf = per_cu >= 3 ? 2 : (per_cu == 2 ? 3 : 5);
+    } else {            // 24 KiB per stage (20, 16 for the lower tiles); three waves per SIMD fit the register file
+        const int per_cu = cdiv(total * want_split, cus);
+        nbuf = per_cu >= 3 ? 2 : (per_cu == 2 ? 3 : 5);
         if (ring_env >= 2 && ring_env <= 5) nbuf = ring_env;
-        if (kv16) launch_pf<4, 1, __half>(a, tiles_n, tiles_t, nbuf);
-        else launch_pf<4, 1, float>(a, tiles_n, tiles_t, nbuf);
+    }
+    // ---- the K split
+    int split_from = total;
+    a.ksplit = 1;
+    a.kb_per_split = a.Kb;
+    if (want_split > 1) {
+        const int kg = shape == 2 ? 2 : 1;
+        a.kb_per_split = cdiv(cdiv(a.Kb, want_split), kg) * kg;   // whole stages per slice
+        a.ksplit = cdiv(a.Kb, a.kb_per_split);
+        if (a.ksplit > 1 && total <= (1 << 16)) {   // (the counter array's size, gemm.hip)
+            split_from = 0;
+            a.slab = (float*)ws_get(WS_SLAB, (size_t)total * a.ksplit * 128 * (32 * tw) * sizeof(float));
+        } else {
+            a.ksplit = 1;
+            a.kb_per_split = a.Kb;
+        }
+    }
+    const int nb = nbuf | ablate_env;
+    if (shape == 2) {
+        if (kv16) launch_pf<4, 2, __half>(a, tiles_n, tiles_t, nb, split_from);
+        else launch_pf<4, 2, float>(a, tiles_n, tiles_t, nb, split_from);
+    } else if (tw == 4) {
+        if (kv16) launch_pf<4, 1, __half, 4>(a, tiles_n, tiles_t, nb, split_from);
+        else launch_pf<4, 1, float, 4>(a, tiles_n, tiles_t, nb, split_from);
+    } else if (tw == 3) {
+        if (kv16) launch_pf<4, 1, __half, 3>(a, tiles_n, tiles_t, nb, split_from);
+        else launch_pf<4, 1, float, 3>(a, tiles_n, tiles_t, nb, split_from);
+    } else {
+        if (kv16) launch_pf<4, 1, __half, 2>(a, tiles_n, tiles_t, nb, split_from);
+        else launch_pf<4, 1, float, 2>(a, tiles_n, tiles_t, nb, split_from);
     }
 }
 
