@@ -8,6 +8,7 @@
 #                                requests the CUs' vector caches send to L2 (bytes INTO the CUs) and L2 hits
 # and prints the per-kernel summaries.
 tag=$1
+cd "$GRAFT_REPO_ROOT" && rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write gpurun_out/${tag}_l2   # one run per directory: the summaries glob
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="bench.py --steps 16 --warmup 2 --cpu-steps 0 --profile-steps 0 --no-variants"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 $B > gpurun_out/${tag}_stats.log 2>&1 || { echo "stats run failed"; tail -5 gpurun_out/${tag}_stats.log; exit 1; }
