@@ -302,15 +302,20 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ h4_t as_h4(u2_t v) { return __builtin_bit_cast(h4_t, v); }
 
-template <int HD, int PF>
+// SOLO: every wave takes an item of its own and walks all of its pages -- for short contexts with many
+// items (a 7B-shape decode batch: 4,096 items of 11 pages), where four waves sharing an item would
+// spend their time in the start-up and the merge rather than in the page loop.
+template <int HD, int PF, bool SOLO = false>
 __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
+    constexpr int STRIDE = SOLO ? 1 : 4;   // pages between two consecutive pages of one wave
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one WORKGROUP per (item, key slice); its four waves take the slice's pages
     // round-robin and merge through LDS at the end
     const unsigned NG = (unsigned)a.NG;
-    const unsigned widx = blockIdx.x;
+    const unsigned widx = SOLO ? blockIdx.x * 4u + (unsigned)wave : blockIdx.x;
+    if (SOLO && widx >= NG * (unsigned)a.nsplit * (unsigned)a.n_runs) return;   // (no barrier in this form)
     const int hg = (int)(widx % NG);
     const unsigned rest = widx / NG;
     const int split = (int)(rest % (unsigned)a.nsplit);
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     const int plim = cvalid ? plast - (ntok - 1 - ctok) : -1;
     const int npages = (plast >> 4) + 1;
     const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
-    const int pg_begin = split * per + wave;            // this wave: pages pg_begin, +4, +8 ...
+    const int pg_begin = split * per + (SOLO ? 0 : wave);   // this wave: pages pg_begin, +STRIDE, ...
     const int pg_end = min(npages, split * per + per);
     const int* table = a.tables + run.w;
     const __half* pk = reinterpret_cast<const __half*>(a.pool_k) + a.layer_off;
@@ -430,26 +435,71 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     // ---- page loop: PF pages in flight per wave
 #pragma unroll
     for (int s = 0; s < PF; s++) {
-        issue(s, pg_begin + 4 * s, blk_of(pg_begin + 4 * s));
+        issue(s, pg_begin + STRIDE * s, blk_of(pg_begin + STRIDE * s));
         __builtin_amdgcn_sched_barrier(0);   // keep issue order = consumption order (counted vmcnt waits)
     }
     int nblk[PF];
 #pragma unroll
-    for (int s = 0; s < PF; s++) nblk[s] = blk_of(pg_begin + 4 * (s + PF));
-    for (int pg = pg_begin; pg < pg_end; pg += 4 * PF) {
+    for (int s = 0; s < PF; s++) nblk[s] = blk_of(pg_begin + STRIDE * (s + PF));
+    for (int pg = pg_begin; pg < pg_end; pg += STRIDE * PF) {
 #pragma unroll
         for (int s = 0; s < PF; s++) {
-            if (pg + 4 * s < pg_end) compute(s, pg + 4 * s);
-            issue(s, pg + 4 * (s + PF), nblk[s]);
-            nblk[s] = blk_of(pg + 4 * (s + 2 * PF));
+            if (pg + STRIDE * s < pg_end) compute(s, pg + STRIDE * s);
+            issue(s, pg + STRIDE * (s + PF), nblk[s]);
+            nblk[s] = blk_of(pg + STRIDE * (s + 2 * PF));
         }
     }
 
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    if constexpr (SOLO) {
+        // ---- one wave owns the item: lane (dim 16n + x, g) holds columns 4g..4g+3, whose (max, sum)
+        // live in the lanes with x = column
+        float Mc[4], Lc[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            Mc[rr] = __shfl(m, 4 * g + rr, 64);
+            Lc[rr] = __shfl(lsum, 4 * g + rr, 64);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int col = 4 * g + rr;
+            const int ct = col >> a.gt_shift, ch = col & (a.GT - 1);
+            if (ct >= ntok) continue;
+            const int t = t0 + ct, h = h0 + ch;
+            if (a.nsplit > 1 && x == 0) {
+                float* pm = a.part_ml + (((size_t)t * a.H + h) * a.nsplit + split) * 2;
+                pm[0] = Mc[rr] * 0.69314718055994530942f;
+                pm[1] = Lc[rr];
+            }
+            const float invL = 1.0f / Lc[rr];
+#pragma unroll
+            for (int n = 0; n < NC; n++) {
+                float o = oacc[n][rr];
+                const int d = 16 * n + x;
+                if (a.nsplit > 1) {
+                    a.part_acc[(((size_t)t * a.H + h) * a.nsplit + split) * HD + d] = o;
+                    continue;
+                }
+                o *= invL;
+                if (a.out_f32) a.out_f32[((size_t)t * a.H + h) * HD + d] = o;
+                if (a.out_a16) {
+                    const int kk = h * HD + d;
+                    const float xv = fminf(fmaxf(o, -65504.f), 65504.f);
+                    const __half hi = __float2half_rn(xv);
+                    const __half lo = __float2half_rn(xv - __half2float(hi));
+                    const size_t tl = ((size_t)(t >> 4) * a.Kb_out + (kk >> 5)) * 2;
+                    const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8 + (kk & 7);
+                    a.out_a16[tl * TILE_HALVES + off] = hi;
+                    a.out_a16[(tl + 1) * TILE_HALVES + off] = lo;
+                }
+            }
+        }
+        return;
+    }
     // ---- merge the four waves through LDS: per column (max, sum), per lane the accumulators
     __shared__ float s_m[4][16], s_l[4][16];
     __shared__ f4_t s_o[4][NC][64];
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
     if (g == 0) {
         s_m[wave][x] = m;
         s_l[wave][x] = lsum;
@@ -555,13 +605,19 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 
 // ------------------------------------------------------------------ launch
 template <int HD>
-static void launch_hd(const AttnKArgs& k, long units, int elem_bytes) {
+static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo) {
     const dim3 block(256);
     if (elem_bytes == 4) {   // fp32 rows: `units` are waves, four independent items per workgroup
         NVLLM_LAUNCH((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
         return;
     }
-    // fp16 pages: `units` are workgroups of four cooperating waves
+    // fp16 pages: `units` are items.  Four cooperating waves per item, or -- many items of few pages --
+    // a wave per item
+    if (solo) {
+        // (two pages in flight per wave; four measured slower: 76.8 against 73.9 us at the 7B shape)
+        NVLLM_LAUNCH((k_paged_attn16<HD, 2, true>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
+        return;
+    }
     const dim3 grid((unsigned)units);
     // pages in flight per wave: two already cover the per-CU fetch rate (one workgroup
     // per CU, ~10 B/clk); deeper rings measured slower
@@ -608,6 +664,10 @@ void launch_paged_attention(const AttnArgs& a) {
     if (nsplit > (pages + min_pages - 1) / min_pages) nsplit = (pages + min_pages - 1) / min_pages;
     if (nsplit < 1) nsplit = 1;
     const long waves = base_items * nsplit;
+    // a wave per item: at least eight items per CU and at most 16 pages each
+    static const int env_solo = getenv("NVLLM_ATTN_SOLO") ? atoi(getenv("NVLLM_ATTN_SOLO")) : -1;
+    bool solo = wg_items && nsplit == 1 && pages <= 16 && waves >= (long)rt().num_cus * 8;
+    if (env_solo >= 0) solo = wg_items && env_solo > 0;
 
     AttnKArgs k;
     k.q = a.q;
@@ -645,13 +705,13 @@ void launch_paged_attention(const AttnArgs& a) {
         const double kvb = (double)a.kv_positions * 2.0 * a.KVH * a.hd * a.pool.elem_bytes;
         ProfScope ps(PC_ATTN, kvb + (double)a.T * a.H * a.hd * 8.0, 4.0 * (double)a.kv_positions * CT * a.H * a.hd);
         switch (a.hd) {
-            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes); break;
-            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes); break;
-            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes); break;
-            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes); break;
-            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes); break;
-            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes); break;
-            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes); break;
+            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes, solo); break;
+            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes, solo); break;
+            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes, solo); break;
+            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes, solo); break;
+            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes, solo); break;
+            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes, solo); break;
+            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes, solo); break;
             default: NVLLM_FATAL("head_dim %d is not supported (16, 32, 48, 64, 80, 96, 128)", a.hd);
         }
     }

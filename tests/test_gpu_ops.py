@@ -211,6 +211,45 @@ def test_fp16_pool_kv_write_and_paged_attention(hip, oracle, hd, H, KVH):
         po.close()
 
 
+@pytest.mark.parametrize("hd,H,KVH,n_seqs", [(128, 16, 16, 160), (64, 32, 32, 96), (48, 12, 6, 400)])
+def test_fp16_pool_attention_many_short_sequences(hip, oracle, hd, H, KVH, n_seqs):
+    """Thousands of (sequence, head group) items of at most 16 pages each -- the shape of a decode batch
+    of a multi-head model at short context -- which the library serves with one wave per item instead
+    of four waves per item.  Contexts cover 1 key, page boundaries and the 16-page limit."""
+    r = rng(hd * 13 + H + n_seqs)
+    L, bs, S = 2, 16, 256
+    ctx = [int(c) for c in r.integers(1, 257, size=n_seqs)]
+    ctx[:6] = [1, 15, 16, 17, 255, 256]
+    maxb = S // bs
+    nb = sum((c + bs - 1) // bs for c in ctx) + 3
+    hip.nvllm_set_kv_elem_bytes(2)
+    try:
+        ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+        perm = r.permutation(nb)
+        cur = 0
+        for s, c in enumerate(ctx):
+            need = (c + bs - 1) // bs
+            blocks = perm[cur:cur + need].tolist()
+            cur += need
+            ph.set_table(s, blocks)
+            po.set_table(s, blocks)
+        h16 = lambda a: a.astype(np.float16).astype(np.float32)
+        kfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        vfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        ph.fill(kfill, vfill)
+        po.fill(kfill, vfill)
+        pos = [c - 1 for c in ctx]
+        sid = list(range(n_seqs))
+        q = r.standard_normal((n_seqs, H * hd)).astype(np.float32)
+        want = util.op_paged_attention_batch(oracle, po, q, 1, pos, sid, S, H, KVH, hd)
+        got = util.op_paged_attention_batch(hip, ph, q, 1, pos, sid, S, H, KVH, hd)
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.abs(want).max() + 2e-6)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(4)
+        ph.close()
+        po.close()
+
+
 @pytest.mark.parametrize("hd,H,KVH", [(64, 32, 4), (48, 6, 6), (128, 8, 2)])
 def test_fp16_pool_attention_over_prefill_chunks(hip, oracle, hd, H, KVH):
     """Hundreds of tokens per call (chunks of several sequences at different depths plus decode
