@@ -700,11 +700,14 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     e5.kind = GemmEpilogue::F32;
     e5.ss_in = ss_head; e5.ss_tiles = ssn; e5.d_in = D; e5.eps = eps;
     g_tp_full_valid = true;
+    // no K split for the classifier (tens of thousands of rows fill the chip); from 112 output rows the
+    // launcher may take the dense-tile kernel instead (0 = its own choice)
+    const int head_split = B >= 112 ? 0 : 1;
     if (!partial) {
         WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
         e5.out = d_logits;
         e5.ldo = V;
-        launch_gemm(wh, m->head, V, a16_head, B, e5, 1, PC_GEMM_HEAD);
+        launch_gemm(wh, m->head, V, a16_head, B, e5, head_split, PC_GEMM_HEAD);
         launch_argmax(d_argmax, d_logits, B, V);
     } else {
         // this rank's vocabulary rows; then either one (max, index) pair per row from every rank,
@@ -716,7 +719,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
             WeightEntry wh{m->head, mine, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
             e5.out = local;
             e5.ldo = ld;
-            launch_gemm(wh, m->head, mine, a16_head, B, e5, 1, PC_GEMM_HEAD);
+            launch_gemm(wh, m->head, mine, a16_head, B, e5, head_split, PC_GEMM_HEAD);
         }
         g_tp_local = local;
         g_tp_slice = ld;
