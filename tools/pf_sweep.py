@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def summarise(path):
     g = defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if "k_gemm_prefill" not in r["Kernel_Name"]:
+        if "k_gemm" not in r["Kernel_Name"]:
             continue
         key = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]))
         g[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
