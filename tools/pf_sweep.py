@@ -2,7 +2,10 @@
 """Sweep the token count of one projection through the library's matmul entry point, for a kernel trace:
     rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/pf_sweep.py --which lm_head --tokens 1024,1408,1591
     python3 tools/pf_sweep.py --summarise OUT/*/*_kernel_trace.csv
-The summary groups the dense-tile kernel's launches by grid size (one group per token count)."""
+The summary groups the projection kernels' launches by grid size (one group per token count).
+The launches of one token count run back to back on the same weights: a matrix of tens of MB is then
+served by the memory-side cache, which a forward pass (2 GB of weights per step) never sees -- fine for
+prefill sizes, where the kernel is not bound by HBM; decode sizes must be confirmed in bench.py."""
 import argparse
 import csv
 import ctypes as C
