@@ -46,7 +46,8 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 
 // FW = 16-row weight blocks per wave (4 or 8), KG = wave groups that split the K-steps, WR = rows of
-// the wave grid (WR x 2 waves per group: 2 -> 128-feature tiles, 4 -> 256-feature tiles), TW = 16-token
+// the wave grid (WR x 2 waves per group: 2 -> 128-feature tiles; 4 -> 256-feature tiles compiles but measured
+// slower on this model's shapes and is not instantiated), TW = 16-token
 // blocks per wave (4, 3 or 2: the tile's height is chosen per launch so that its rounds of workgroups fill)
 template <int FW, int KG, int WR = 2, int TW = 4>
 struct PfGeom {
