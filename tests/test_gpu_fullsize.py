@@ -86,6 +86,29 @@ def _kv_close(g, o, fp16_pool):
                 assert worst < 2e-5 * scale, worst
 
 
+def test_256_greedy_steps_at_the_benchmark_shape(hip, oracle, tinyllama):
+    """The acceptance run at full width: greedy tokens identical to the CPU path for 256 steps (four
+    sequences with staggered prompts so that prefill chunks and decode rows share passes; fp16 page
+    pool, arg-max hand-off as in the benchmark).  Reference loop: main.c:259-419."""
+    path, shape = tinyllama
+    prompts = synth.make_requests(4, 5, 40, shape.vocab_size, seed=23)
+    kw = dict(n_new=256, arrivals=[0, 0, 2, 5], chunk_size=16, temperature=0.0, max_steps=400)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    before = hip.nvllm_get_kv_elem_bytes()
+    hip.nvllm_set_kv_elem_bytes(2)
+    hip.nvllm_set_logits_mode(1)
+    try:
+        g = util.run_engine(hip, path, prompts, **kw)
+    finally:
+        hip.nvllm_set_logits_mode(0)
+        hip.nvllm_set_kv_elem_bytes(before)
+    assert all(len(h) == len(p) + 256 for h, p in zip(o["histories"], prompts))
+    for a, b in zip(g["histories"], o["histories"]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(g["tables"], o["tables"]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_512_token_chunks_then_decode_beyond_1024_at_the_benchmark_shape(hip, oracle, tinyllama):
     """What the benchmark times, as a forward pass against the oracle: 1040-token prompts forwarded in
     512-token chunks (two sequences per pass: 1024 tokens through the dense-contraction projection
