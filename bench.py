@@ -93,7 +93,9 @@ class DistEnv:
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # NVLLM_BENCH_BACKEND=gloo: rehearsal of an N-rank run on a box with fewer GPUs than ranks
+                # (the ranks then share devices, see `device_index`; the numbers mean nothing, the plumbing runs)
+                backend = os.environ.get("NVLLM_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             self.backend = backend
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
@@ -102,6 +104,13 @@ class DistEnv:
             self.device = torch.device("cuda", self.local_rank) if backend == "nccl" else torch.device("cpu")
         if want_gpus != self.world and self.rank == 0:
             print(f"bench: --gpus {want_gpus} but WORLD_SIZE is {self.world}; using {self.world}", file=sys.stderr)
+
+    def device_index(self) -> int:
+        """The GPU of this rank: LOCAL_RANK, wrapped when a rehearsal runs more ranks than the box has GPUs."""
+        if self.world == 1:
+            return self.local_rank
+        n = self.torch.cuda.device_count()   # (does not initialise the GPU)
+        return self.local_rank % n if n > 0 else self.local_rank
 
     def barrier(self):
         if self.dist:
@@ -173,7 +182,7 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
     if profile_steps is not None:
         args.profile_steps = profile_steps
     lib = capi.load_hip()           # raises if the HIP library is not built: no fall-back
-    lib.nvllm_set_device(env.local_rank)
+    lib.nvllm_set_device(env.device_index())
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
     lib.nvllm_set_logits_mode(0 if args.logits_host else 1)   # default: only token ids return to the host
     if args.tp and not getattr(run_gpu, "_tp_up", False):

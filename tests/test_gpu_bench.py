@@ -55,3 +55,21 @@ def test_tensor_parallel_line_with_one_rank(tmp_path):
     _common_fields(d)
     assert d["scaling"] == "strong" and d["config"]["parallelism"] == "tp1" and "TP=1" in d["metric"]
     assert d["cpu_baseline"] is None and d["variants"] is None
+
+
+def test_two_data_parallel_ranks_rehearsed_on_one_gpu(tmp_path):
+    """The launcher contract with two ranks (`python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2`): both replicas share this box's one GPU and meet through gloo, so the throughput means
+    nothing -- what is checked is the plumbing an 8-GPU run depends on: one shared model file, per-rank
+    request shards, the MAX-over-ranks timing and one JSON line from rank 0 with the whole-job aggregate."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model-dir", str(tmp_path)] + COMMON + \
+          ["--cpu-steps", "0", "--no-variants"]
+    env = dict(os.environ, NVLLM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
