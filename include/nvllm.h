@@ -197,6 +197,14 @@ void nvllm_engine_destroy(NvllmEngine* e);
 int nvllm_engine_set_request(NvllmEngine* e, int seq, const int* prompt, int n_prompt,
                              int n_new, int arrival_step);
 
+/* Measurement aid (no counterpart in the reference): treat the first `upto` prompt tokens of a sequence
+ * that has not started yet as already processed -- its blocks are allocated in the loop's order
+ * (main.c:320-335), the K/V rows of those positions keep whatever the pool holds, and the sequence
+ * continues at position `upto` (at most n_prompt - 1) with prompt[upto].  A CPU timing of decode steps at
+ * a long context uses it instead of a prefill that would take the CPU half an hour; results of such a
+ * run are not a model's output.  Returns the position set, or -1 on bad input. */
+int nvllm_engine_skip_prefill(NvllmEngine* e, int seq, int upto);
+
 /* One iteration of the loop at main.c:259-419.  Returns 1 while work remains,
  * 0 once every sequence has finished (or the step cap was hit). */
 int nvllm_engine_step(NvllmEngine* e);

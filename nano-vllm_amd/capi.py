@@ -124,6 +124,7 @@ _COMMON = {
     "nvllm_engine_create": (_P, [C.c_char_p, _I, C.POINTER(EngineOptions)]),
     "nvllm_engine_destroy": (_V, [_P]),
     "nvllm_engine_set_request": (_I, [_P, _I, c_int_p, _I, _I, _I]),
+    "nvllm_engine_skip_prefill": (_I, [_P, _I, _I]),
     "nvllm_engine_step": (_I, [_P]),
     "nvllm_engine_run": (_I, [_P, _I]),
     "nvllm_engine_global_step": (_I, [_P]),
@@ -273,6 +274,13 @@ class Engine:
                                                n_new, arrival_step)
         if rc != 0:
             raise ValueError(f"bad request for seq {seq}")
+
+    def skip_prefill(self, seq, upto) -> int:
+        """Measurement aid: start `seq` at position `upto` with its blocks allocated and the pool rows as they are."""
+        rc = self.lib.nvllm_engine_skip_prefill(self.h, seq, upto)
+        if rc < 0:
+            raise ValueError(f"cannot skip the prefill of seq {seq}")
+        return rc
 
     def step(self) -> int:
         return self.lib.nvllm_engine_step(self.h)

@@ -222,6 +222,26 @@ int nvllm_engine_set_request(NvllmEngine* e, int seq, const int* prompt, int n_p
     return 0;
 }
 
+int nvllm_engine_skip_prefill(NvllmEngine* e, int seq, int upto) {
+    if (!e || seq < 0 || seq >= e->n_seqs) return -1;
+    Sequence* s = &e->seqs[seq];
+    if (s->status != SEQ_WAITING || s->pos != 0 || !s->prompt_tokens || upto < 0) return -1;
+    if (upto > s->num_prompt_tokens - 1) upto = s->num_prompt_tokens - 1;
+    const int bs = g_kv_manager.block_size;
+    for (int p = 0; p < upto; p++) {
+        if (p % bs == 0) {                                  /* main.c:322-335 */
+            const int blk = alloc_block(&g_kv_manager);
+            if (blk == -1) return -1;
+            s->table.block_indices[p / bs] = blk;
+            s->table.num_blocks++;
+            trace_push(e, seq, p / bs, blk);
+        }
+    }
+    s->pos = upto;
+    s->current_token = s->prompt_tokens[upto];
+    return upto;
+}
+
 static void release_blocks(NvllmEngine* e, Sequence* s) {
     /* extension: hand a finished sequence's blocks back, last allocated first */
     for (int b = s->table.num_blocks - 1; b >= 0; b--) free_block(&g_kv_manager, s->table.block_indices[b]);

@@ -2,6 +2,7 @@
 oracle: batch construction, block allocation order and the scheduler quirks of
 reference src/main.c:259-419."""
 import numpy as np
+import pytest
 
 from nvllm_amd import capi, synth
 from tests import util
@@ -76,3 +77,26 @@ def test_sampler_rows_and_ties(oracle):
     oracle.build_sampler(C.byref(s), 8, 0.0, 0.9, 1)
     row = np.array([0.5, 2.0, 2.0, -1.0, 2.0, 0.0, 1.9, 2.0], np.float32)
     assert oracle.sample(C.byref(s), row.ctypes.data) == 1      # strict '>' keeps the first maximum
+
+
+def test_skip_prefill_starts_a_sequence_at_a_position(oracle, tmp_models):
+    """The measurement aid behind the CPU baseline: blocks for the skipped positions are allocated in
+    order, the sequence continues with a decode row at that position, and nothing else changes."""
+    path, shape = tmp_models("tiny")
+    e = capi.Engine(oracle, path, 2, chunk_size=16, temperature=0.0, max_seq_len=128)
+    prompts = synth.make_requests(2, 40, 40, shape.vocab_size, seed=5)
+    for i, p in enumerate(prompts):
+        e.set_request(i, p, 3, 0)
+    assert e.skip_prefill(0, 39) == 39
+    assert e.skip_prefill(1, 1000) == 39                      # clamped to the last prompt token
+    assert list(e.block_table(0)) == [0, 1, 2] and list(e.block_table(1)) == [3, 4, 5]
+    e.step()
+    b = e.last_batch()
+    assert list(b["pos"]) == [39, 39] and list(b["tokens"]) == [prompts[0][39], prompts[1][39]]
+    while e.step():
+        pass
+    assert all(len(e.history(i)) == 43 for i in range(2))
+    e.step()
+    with pytest.raises(ValueError):
+        e.skip_prefill(0, 5)                                  # only before a sequence has started
+    e.close()

@@ -42,7 +42,9 @@ def test_data_parallel_line(tmp_path):
     _common_fields(d)
     assert d["scaling"] == "weak" and d["config"]["parallelism"] == "single"
     c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["context_tokens"] == [2, 4]
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    lo, hi = c["context_tokens"]                     # the CPU leg decodes at the GPU run's context
+    assert hi - lo == 2 and lo > 40
     v = d["variants"]
     assert set(v) == {"fp32_kv_pool", "logits_rows_to_host", "fp32_kv_pool_and_logits_rows_to_host"}
     assert all(x["value"] > 0 for x in v.values())
