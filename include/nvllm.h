@@ -140,11 +140,12 @@ int  nvllm_tp_world(void);
  * whose scheduling does not depend on the sampled token VALUES (greedy decoding, sequences that
  * end by length) can keep the GPU busy across steps: enqueue pass n+1 before collecting pass n,
  * naming for each decode row the output row of pass n whose arg-max it continues with; the GPU
- * takes those token ids from HBM.  Only in NVLLM_LOGITS_ARGMAX mode (host logits rows belong to
- * one pass at a time).  Same arguments as transformer_batch (src/model.c:347-419) plus
+ * takes those token ids from HBM.  In NVLLM_LOGITS_HOST mode the logits rows of a pass are copied to
+ * the `logits` member of the RunState given to it, complete once the pass is collected: passes in flight
+ * at the same time need a RunState each.  Same arguments as transformer_batch (src/model.c:347-419) plus
  *   token_src[t]  -1: the token id is tokens[t];  k >= 0: it is the arg-max of output row k of
  *                 the pass enqueued immediately before this one (null = all -1).
- * Returns a ticket (>= 0), or -1 when the mode does not allow it or num_tokens == 0.  The host
+ * Returns a ticket (>= 0), or -1 on a null argument or num_tokens == 0.  The host
  * arrays may be reused as soon as the call returns.  At most 4 passes may be in flight. */
 long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
                            int num_outputs, const int* token_src, Config* p, RunState* s, Weights* w,

@@ -751,7 +751,7 @@ void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, 
 // include/nvllm.h: the forward pass in two halves, for a driver that keeps the GPU busy across steps
 long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices, int num_outputs,
                            const int* token_src, Config* p, RunState* s, Weights* w, BlockTable** block_tables) {
-    if (rt().logits_mode != NVLLM_LOGITS_ARGMAX) return -1;   // host logits rows belong to one pass at a time
+    // (with host logits rows, every pass in flight needs a RunState of its own: its rows land in s->logits)
     if (num_tokens <= 0 || num_outputs < 0 || !tokens || !pos_arr || !seq_ids || !p || !s || !w || !block_tables) return -1;
     return enqueue_pass(tokens, num_tokens, pos_arr, seq_ids, output_indices, num_outputs, p, s, w, block_tables, token_src);
 }

@@ -33,11 +33,14 @@ __attribute__((weak)) KVCacheManager g_kv_manager;
  * (the reference has no free_model and simply leaks at exit). */
 extern void nvllm_free_model(Weights* w) __attribute__((weak));
 /* Optional: a backend that can run the forward pass in two halves (include/nvllm.h).  With greedy
- * decoding and the arg-max hand-off nothing the scheduler decides depends on the VALUES of the
- * sampled tokens (sequences end by length), so the driver enqueues pass n+1 -- decode rows take
- * their token from pass n's arg-max on the GPU -- before it collects pass n: the GPU never waits
- * for the host between steps.  Every query of sampled tokens first collects what is in flight, so
- * the driver's observable state is that of the step-by-step loop. */
+ * decoding nothing the scheduler decides depends on the VALUES of the sampled tokens (sequences end
+ * by length), so the driver enqueues pass n+1 -- decode rows take their token from pass n's arg-max
+ * on the GPU -- before it collects pass n: the GPU never waits for the host between steps.  With the
+ * arg-max hand-off the collected indices are the tokens; with logits rows on the host the tokens are
+ * still the sampler's, taken from the collected pass's rows while the next pass runs (two RunStates
+ * alternate), and checked against the index the GPU continued with.  Every query of sampled tokens
+ * or logits first collects what is in flight, so the driver's observable state is that of the
+ * step-by-step loop. */
 extern long nvllm_forward_enqueue(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
                                   int num_outputs, const int* token_src, Config* p, RunState* s, Weights* w,
                                   BlockTable** block_tables) __attribute__((weak));
@@ -48,7 +51,9 @@ struct NvllmEngine {
     NvllmEngineOptions opt;
     Config config;
     Weights weights;
-    RunState state;
+    RunState state;          /* the step-by-step loop's; pass slot 0 of the two-halves loop */
+    RunState state2;         /* pass slot 1 (allocated on first use: host logits rows of two passes in flight) */
+    int state2_ready, flip, pend_state, seen_state;
     Sampler sampler;
     int n_seqs;
     Sequence* seqs;
@@ -156,14 +161,28 @@ NvllmEngine* nvllm_engine_create(const char* model_path, int n_seqs, const Nvllm
 static void engine_flush(NvllmEngine* e) {
     if (!e->pend_active) return;
     const int n = nvllm_forward_collect(e->pend_ticket, e->collected, e->n_seqs);
+    const int host_rows = nvllm_get_logits_mode() != NVLLM_LOGITS_ARGMAX;
+    const RunState* st = e->pend_state ? &e->state2 : &e->state;
+    e->seen_state = e->pend_state;
+    const double t0 = now_seconds();
     for (int k = 0; k < n && k < e->pend_outputs; k++) {
         Sequence* s = &e->seqs[e->pend_seq[k]];
-        const int next = e->collected[k];
+        int next = e->collected[k];
+        if (host_rows) {
+            /* the token is the sampler's, from the row on the host (main.c:377); the pass after this
+             * one was fed the GPU's arg-max of the same row, which follows the same rule */
+            next = sample(&e->sampler, st->logits + (size_t)k * e->config.vocab_size);
+            if (next != e->collected[k]) {
+                fprintf(stderr, "nvllm engine: host and device arg-max disagree on output %d (%d vs %d)\n", k, next, e->collected[k]);
+                exit(1);
+            }
+        }
         if (e->pend_hist_pos[k] >= 0) s->output_history[e->pend_hist_pos[k]] = next;
         s->current_token = next;
         e->batch_sampled[k] = next;
         e->row_of_seq[e->pend_seq[k]] = -1;
     }
+    if (host_rows) e->stats.sample_seconds += now_seconds() - t0;
     e->pend_active = 0;
 }
 
@@ -191,6 +210,7 @@ void nvllm_engine_destroy(NvllmEngine* e) {
     free(e->trace);
     free(e->sampler.probindex);
     free_run_state(&e->state);
+    if (e->state2_ready) free_run_state(&e->state2);
     free_ops();
     free_kv_cache_manager(&g_kv_manager);
     if (nvllm_free_model) nvllm_free_model(&e->weights);
@@ -250,10 +270,9 @@ static void release_blocks(NvllmEngine* e, Sequence* s) {
 
 int nvllm_engine_step(NvllmEngine* e) {
     if (!e || e->finished) return 0;
-    /* two-halves mode: greedy, arg-max hand-off, and a backend that offers it */
+    /* two-halves mode: greedy, and a backend that offers it */
     const int two_halves = nvllm_forward_enqueue && nvllm_forward_collect && nvllm_get_logits_mode &&
-                           e->sampler.temperature == 0.0f && nvllm_get_logits_mode() == NVLLM_LOGITS_ARGMAX &&
-                           !getenv("NVLLM_ENGINE_STEPWISE");
+                           e->sampler.temperature == 0.0f && !getenv("NVLLM_ENGINE_STEPWISE");
     if (!two_halves) engine_flush(e);
     int any_src = 0;
     int all_finished = 1;
@@ -339,9 +358,15 @@ int nvllm_engine_step(NvllmEngine* e) {
 
     if (two_halves) {
         const double t0 = now_seconds();
+        /* the two passes in flight alternate between two RunStates (their host logits rows) */
+        if (e->flip && !e->state2_ready) {
+            malloc_run_state(&e->state2, &e->config);
+            e->state2_ready = 1;
+        }
+        RunState* st = e->flip ? &e->state2 : &e->state;
         const long ticket = nvllm_forward_enqueue(e->batch_tokens, batch_count, e->batch_pos, e->batch_seq_ids,
                                                   e->batch_output_indices, output_count, any_src ? e->batch_token_src : NULL,
-                                                  &e->config, &e->state, &e->weights, e->batch_block_tables);
+                                                  &e->config, st, &e->weights, e->batch_block_tables);
         if (ticket < 0) {
             fprintf(stderr, "nvllm engine: the backend refused to enqueue the pass\n");
             exit(1);
@@ -368,6 +393,8 @@ int nvllm_engine_step(NvllmEngine* e) {
             }
         }
         e->pend_active = 1;
+        e->pend_state = e->flip;
+        e->flip ^= 1;
         e->pend_ticket = ticket;
         e->pend_outputs = output_count;
         e->last_batch_count = batch_count;
@@ -395,6 +422,7 @@ int nvllm_engine_step(NvllmEngine* e) {
     }
 
     /* forward pass (main.c:367-369) */
+    e->seen_state = 0;
     const double t0 = now_seconds();
     transformer_batch(e->batch_tokens, batch_count, e->batch_pos, e->batch_seq_ids,
                       e->batch_output_indices, output_count, &e->config, &e->state, &e->weights,
@@ -502,7 +530,10 @@ int nvllm_engine_last_batch(const NvllmEngine* e, int* tokens, int* pos, int* se
     return e->last_batch_count;
 }
 
-const float* nvllm_engine_logits(const NvllmEngine* e) { return e->state.logits; }
+const float* nvllm_engine_logits(const NvllmEngine* e) {
+    engine_flush((NvllmEngine*)e);
+    return e->seen_state ? e->state2.logits : e->state.logits;
+}
 
 int nvllm_engine_alloc_trace(const NvllmEngine* e, int* out, int cap_triples) {
     const int n = e->trace_len < cap_triples ? e->trace_len : cap_triples;

@@ -1,4 +1,4 @@
-"""The driver's two-halves mode (greedy, arg-max hand-off): pass n+1 is enqueued before pass n is
+"""The driver's two-halves mode (greedy; arg-max hand-off or logits rows on the host): pass n+1 is enqueued before pass n is
 collected and decode rows take their token from the previous pass's arg-max on the GPU.  Its
 histories, allocation traces and per-step records must be those of the step-by-step loop and of
 the CPU oracle -- including the reference's quirk that a sequence whose chunk boundary leaves one
@@ -75,6 +75,38 @@ def test_two_halves_mode_equals_the_stepwise_loop_and_the_oracle(hip, oracle, tm
             np.testing.assert_array_equal(a, b)
     for key in blind["last"]:
         np.testing.assert_array_equal(blind["last"][key], stepwise["last"][key])
+
+
+def test_two_halves_mode_with_logits_rows_on_the_host(hip, oracle, tmp_models):
+    """The reference's own hand-off (logits rows in host memory, the sampler reads them): passes still
+    overlap -- two RunStates alternate, the tokens come from sample() on the collected pass's rows -- and
+    an observer who reads the rows mid-run finds those of the pass just collected."""
+    path, shape = tmp_models("stories15M", max_seq_len=256, vocab_size=2000)
+    n = 7
+    prompts = _requests(shape, n, seed=77)
+    n_new = [6 + 2 * (i % 3) for i in range(n)]
+    arrivals = [(3 * i) % 5 for i in range(n)]
+    opts = dict(chunk_size=16, temperature=0.0, max_steps=400)
+    want = util.run_engine(oracle, path, prompts, n_new, arrivals=arrivals, collect_logits=True, **opts)
+    assert hip.nvllm_get_logits_mode() == 0
+    blind = _run_blind(hip, path, prompts, n_new, arrivals, pause_at=(4, 9), **opts)
+    os.environ["NVLLM_ENGINE_STEPWISE"] = "1"
+    try:
+        stepwise = _run_blind(hip, path, prompts, n_new, arrivals, pause_at=(4, 9), **opts)
+    finally:
+        del os.environ["NVLLM_ENGINE_STEPWISE"]
+    watched = util.run_engine(hip, path, prompts, n_new, arrivals=arrivals, collect_logits=True, **opts)
+    assert blind["steps"] == stepwise["steps"] == len(want["steps"])
+    for got in (blind, stepwise, watched):
+        np.testing.assert_array_equal(got["trace"], want["trace"])
+        for a, b in zip(got["histories"], want["histories"]):
+            np.testing.assert_array_equal(a, b)
+    for sg, so in zip(watched["steps"], want["steps"]):            # rows read after every step: the step's own
+        assert np.abs(sg["logits"] - so["logits"]).max() < 2e-4
+    for k in (4, 9):
+        (lb_a, h_a), (lb_b, h_b) = blind["seen"][k], stepwise["seen"][k]
+        for key in lb_a:
+            np.testing.assert_array_equal(lb_a[key], lb_b[key])
 
 
 def test_forward_in_two_halves_through_the_c_abi(hip, tmp_models):
