@@ -61,6 +61,21 @@ int nvllm_argmax_rows(int* out, const float* logits, int num_rows, int vocab_siz
 void nvllm_set_kv_elem_bytes(int bytes);
 int  nvllm_get_kv_elem_bytes(void);
 
+/* -------------------------------------------------- one launch per decode step */
+/* No counterpart in the reference, whose layer loop (src/model.c:358-394) calls one operator
+ * after the other.  With the switch on (default; environment NVLLM_DECODE_CHAIN=0 turns it off
+ * at start-up) transformer_batch runs ALL layers of a decode-sized step -- at most 64 tokens,
+ * fp16 KV pool, the whole model on this GPU, a model shape the library has a tiling for -- as one
+ * kernel launch whose workgroups hand their tiles to each other through arrival counters, so that
+ * the weights of the next projection are already travelling while the current one is reduced and
+ * stored; every other step takes one launch per operator as before.  Results are identical either
+ * way (same tiles, same summation order).  The one-launch form needs every CU of the GPU for
+ * itself: two processes that drive the same GPU must turn it off.
+ * nvllm_decode_chain_launches() counts the steps that took the one-launch form. */
+void nvllm_set_decode_chain(int on);
+int  nvllm_get_decode_chain(void);
+long nvllm_decode_chain_launches(void);
+
 /* ------------------------------------------------ matmul without allocation */
 /* No counterpart in the reference.  For callers that cannot allocate device memory:
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.

@@ -166,6 +166,9 @@ _HIP_ONLY = {
                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nvllm_free_model": (_V, [C.POINTER(Weights)]),
     "nvllm_matmul_noalloc": (_I, [_P, _P, _P, _I, _I, _I]),
+    "nvllm_set_decode_chain": (_V, [_I]),
+    "nvllm_get_decode_chain": (_I, []),
+    "nvllm_decode_chain_launches": (_L, []),
     "nvllm_tp_shard": (_I, [C.POINTER(Config), _I, _I, C.POINTER(TpShard)]),
     "nvllm_tp_unique_id": (_I, [_P]),
     "nvllm_tp_init": (_I, [_I, _I, _P]),

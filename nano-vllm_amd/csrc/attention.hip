@@ -25,32 +25,11 @@
 // (acc, max, sum) partials that k_attn_combine merges.
 //
 // fp16 pool (pages in operand order), k_paged_attn16: see the comment above it.
-#include "nvllm_internal.h"
+#include "attn_tile.h"
 
 namespace nvllm {
 
 typedef float f4_t __attribute__((ext_vector_type(4)));
-
-struct AttnKArgs {
-    const float* q;
-    const void* pool_k;
-    const void* pool_v;
-    long layer_off;   // elements
-    long rowstride;   // elements between consecutive positions of a page (KVH * hd)
-    int page;         // positions per page as seen by the kernel (16)
-    const int* tables;
-    const int4* runs; // (first token, token count, last position, block-table offset) per item
-    int n_runs;
-    int H, KVH, GT, CT;
-    int NG, group, gt_shift;
-    int nsplit;
-    float scale;
-    float* out_f32;
-    __half* out_a16;
-    int Kb_out;
-    float* part_acc;  // [t][h][split][HD]
-    float* part_ml;   // [t][h][split][2]
-};
 
 struct alignas(16) H8 {
     __half v[8];
@@ -297,259 +276,32 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
 // v_exp_f32 per probability).  Pages beyond the slice are requested through a
 // zero-length buffer descriptor: the hardware returns zeros without touching memory,
 // so the prefetch ring needs no branches and no clamped re-reads.
-typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ h4_t as_h4(u2_t v) { return __builtin_bit_cast(h4_t, v); }
-
+// The work of one wave on one item is Attn16Wave (attn_tile.h).
+//
 // SOLO: every wave takes an item of its own and walks all of its pages -- for short contexts with many
 // items (a 7B-shape decode batch: 4,096 items of 11 pages), where four waves sharing an item would
 // spend their time in the start-up and the merge rather than in the page loop.
 template <int HD, int PF, bool SOLO = false>
 __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     constexpr int STRIDE = SOLO ? 1 : 4;   // pages between two consecutive pages of one wave
-    constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // one WORKGROUP per (item, key slice); its four waves take the slice's pages
     // round-robin and merge through LDS at the end
-    const unsigned NG = (unsigned)a.NG;
     const unsigned widx = SOLO ? blockIdx.x * 4u + (unsigned)wave : blockIdx.x;
-    if (SOLO && widx >= NG * (unsigned)a.nsplit * (unsigned)a.n_runs) return;   // (no barrier in this form)
-    const int hg = (int)(widx % NG);
-    const unsigned rest = widx / NG;
-    const int split = (int)(rest % (unsigned)a.nsplit);
-    const int4 run = a.runs[rest / (unsigned)a.nsplit];
-    const int t0 = run.x, ntok = run.y, plast = run.z;
-    const int h0 = hg * a.GT;
-    const int kvh = (int)((unsigned)h0 / (unsigned)a.group);
-
-    const int x = lane & 15, g = lane >> 4;
-    const int ctok = x >> a.gt_shift, chead = x & (a.GT - 1);
-    const bool cvalid = ctok < ntok;
-    const int tcol = t0 + (cvalid ? ctok : 0);
-    const int plim = cvalid ? plast - (ntok - 1 - ctok) : -1;
-    const int npages = (plast >> 4) + 1;
-    const int per = (int)((unsigned)(npages + a.nsplit - 1) / (unsigned)a.nsplit);
-    const int pg_begin = split * per + (SOLO ? 0 : wave);   // this wave: pages pg_begin, +STRIDE, ...
-    const int pg_end = min(npages, split * per + per);
-    const int* table = a.tables + run.w;
-    const __half* pk = reinterpret_cast<const __half*>(a.pool_k) + a.layer_off;
-    const __half* pv = reinterpret_cast<const __half*>(a.pool_v) + a.layer_off;
-
-    // Q as the B operand: lane (col = x, dims 16c + 4g .. +3), split into fp16 hi + lo
-    h4_t qh[NC], ql[NC];
-    {
-        const float* qr = a.q + ((size_t)tcol * a.H + h0 + chead) * HD + 4 * g;
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const float4 f = cvalid ? ld4(qr + 16 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float fv[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float cl = fminf(fmaxf(fv[e], -65504.f), 65504.f);
-                qh[c][e] = (_Float16)cl;
-                ql[c][e] = (_Float16)(cl - (float)qh[c][e]);
-            }
-        }
-    }
-    const float sl2 = a.scale * 1.44269504088896340736f;   // scores in the log2 domain
-
-    float m = -INFINITY, lsum = 0.f;
-    f4_t oacc[NC];
-#pragma unroll
-    for (int n = 0; n < NC; n++) oacc[n] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-    u2_t kr[PF][NC], vr[PF][NC];
-    const int voff = lane * 8;
-    // block id of a page of this wave (a scalar load); looked up one ring turn before the
-    // page is requested, so that the request never waits for the table
-    auto blk_of = [&](int pg) -> int { return table[pg < pg_end ? pg : 0]; };
-    auto issue = [&](int slot, int pg, int blk) {
-        const bool ok = pg < pg_end;   // wave-uniform
-        const long block = blk;
-        const long off = kv16_page(block, kvh, a.KVH, HD);
-        const int bytes = ok ? 32 * HD : 0;
-        auto rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pk + off), 0, bytes, 0x00020000);
-        auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<__half*>(pv + off), 0, bytes, 0x00020000);
-#pragma unroll
-        for (int c = 0; c < NC; c++) kr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rk, voff + 512 * c, 0, 0);
-#pragma unroll
-        for (int c = 0; c < NC; c++) vr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rv, voff + 512 * c, 0, 0);
-    };
-
-    auto compute = [&](int slot, int pg) {
-        // ---- scores: independent accumulator chains for the hi and lo halves of Q
-        f4_t s0 = f4_t{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-#pragma unroll
-        for (int c = 0; c < NC; c += 2) {
-            s0 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c]), qh[c], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c]), ql[c], s1, 0, 0, 0);
-            if (c + 1 < NC) {
-                s2 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c + 1]), qh[c + 1], s2, 0, 0, 0);
-                s3 = __builtin_amdgcn_mfma_f32_16x16x16f16(as_h4(kr[slot][c + 1]), ql[c + 1], s3, 0, 0, 0);
-            }
-        }
-        float sc[4];
-        float mx = -INFINITY;
-        const int kfirst = pg * 16 + 4 * g;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const float v = ((s0[rr] + s2[rr]) + (s1[rr] + s3[rr])) * sl2;
-            sc[rr] = (kfirst + rr <= plim) ? v : -INFINITY;
-            mx = fmaxf(mx, sc[rr]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__any(mx > m)) {   // some column's running maximum rises (rare after the first pages)
-            const float mn = fmaxf(m, mx);
-            const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m - mn);
-            lsum *= alpha;
-            m = mn;
-            // the accumulators hold columns 4g..4g+3: fetch their factors from lanes 4g+r
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const float ar = __shfl(alpha, 4 * g + rr, 64);
-#pragma unroll
-                for (int n = 0; n < NC; n++) oacc[n][rr] *= ar;
-            }
-        }
-        const float msafe = fmaxf(m, -1.0e30f);   // nothing visible yet: exp2(-inf - finite) = 0, no NaN
-        h4_t ph, pl;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const float p = __builtin_amdgcn_exp2f(sc[rr] - msafe);
-            lsum += p;
-            ph[rr] = (_Float16)p;
-            pl[rr] = (_Float16)(p - (float)ph[rr]);
-        }
-        // ---- O += P V
-#pragma unroll
-        for (int n = 0; n < NC; n++)
-            oacc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, as_h4(vr[slot][n]), oacc[n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < NC; n++)
-            oacc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(pl, as_h4(vr[slot][n]), oacc[n], 0, 0, 0);
-    };
-
-    // ---- page loop: PF pages in flight per wave
-#pragma unroll
-    for (int s = 0; s < PF; s++) {
-        issue(s, pg_begin + STRIDE * s, blk_of(pg_begin + STRIDE * s));
-        __builtin_amdgcn_sched_barrier(0);   // keep issue order = consumption order (counted vmcnt waits)
-    }
-    int nblk[PF];
-#pragma unroll
-    for (int s = 0; s < PF; s++) nblk[s] = blk_of(pg_begin + STRIDE * (s + PF));
-    for (int pg = pg_begin; pg < pg_end; pg += STRIDE * PF) {
-#pragma unroll
-        for (int s = 0; s < PF; s++) {
-            if (pg + STRIDE * s < pg_end) compute(s, pg + STRIDE * s);
-            issue(s, pg + STRIDE * (s + PF), nblk[s]);
-            nblk[s] = blk_of(pg + STRIDE * (s + 2 * PF));
-        }
-    }
-
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
+    if (SOLO && widx >= (unsigned)a.NG * (unsigned)a.nsplit * (unsigned)a.n_runs) return;   // (no barrier in this form)
+    Attn16Wave<HD, PF, STRIDE, false> w;
+    w.setup(a, widx, SOLO ? 0 : wave, lane, 0);
+    w.load_q();
+    w.start();
+    w.loop();
     if constexpr (SOLO) {
-        // ---- one wave owns the item: lane (dim 16n + x, g) holds columns 4g..4g+3, whose (max, sum)
-        // live in the lanes with x = column
-        float Mc[4], Lc[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            Mc[rr] = __shfl(m, 4 * g + rr, 64);
-            Lc[rr] = __shfl(lsum, 4 * g + rr, 64);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int col = 4 * g + rr;
-            const int ct = col >> a.gt_shift, ch = col & (a.GT - 1);
-            if (ct >= ntok) continue;
-            const int t = t0 + ct, h = h0 + ch;
-            if (a.nsplit > 1 && x == 0) {
-                float* pm = a.part_ml + (((size_t)t * a.H + h) * a.nsplit + split) * 2;
-                pm[0] = Mc[rr] * 0.69314718055994530942f;
-                pm[1] = Lc[rr];
-            }
-            const float invL = 1.0f / Lc[rr];
-#pragma unroll
-            for (int n = 0; n < NC; n++) {
-                float o = oacc[n][rr];
-                const int d = 16 * n + x;
-                if (a.nsplit > 1) {
-                    a.part_acc[(((size_t)t * a.H + h) * a.nsplit + split) * HD + d] = o;
-                    continue;
-                }
-                o *= invL;
-                if (a.out_f32) a.out_f32[((size_t)t * a.H + h) * HD + d] = o;
-                if (a.out_a16) {
-                    const int kk = h * HD + d;
-                    const float xv = fminf(fmaxf(o, -65504.f), 65504.f);
-                    const __half hi = __float2half_rn(xv);
-                    const __half lo = __float2half_rn(xv - __half2float(hi));
-                    const size_t tl = ((size_t)(t >> 4) * a.Kb_out + (kk >> 5)) * 2;
-                    const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8 + (kk & 7);
-                    a.out_a16[tl * TILE_HALVES + off] = hi;
-                    a.out_a16[(tl + 1) * TILE_HALVES + off] = lo;
-                }
-            }
-        }
-        return;
-    }
-    // ---- merge the four waves through LDS: per column (max, sum), per lane the accumulators
-    __shared__ float s_m[4][16], s_l[4][16];
-    __shared__ f4_t s_o[4][NC][64];
-    if (g == 0) {
-        s_m[wave][x] = m;
-        s_l[wave][x] = lsum;
-    }
-#pragma unroll
-    for (int n = 0; n < NC; n++) s_o[wave][n][lane] = oacc[n];
-    __syncthreads();
-    // wave w finishes dim blocks n = w, w+4, ...; lane (dim 16n + x, g) owns columns 4g..4g+3
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int col = 4 * g + rr;
-        const int ct = col >> a.gt_shift, ch = col & (a.GT - 1);
-        if (ct >= ntok) continue;
-        const int t = t0 + ct, h = h0 + ch;
-        float M = fmaxf(fmaxf(s_m[0][col], s_m[1][col]), fmaxf(s_m[2][col], s_m[3][col]));
-        const float Ms = fmaxf(M, -1.0e30f);
-        float f[4], L = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            f[w] = __builtin_amdgcn_exp2f(s_m[w][col] - Ms);   // a wave without visible keys: exp2(-inf) = 0
-            L = fmaf(s_l[w][col], f[w], L);
-        }
-        if (a.nsplit > 1 && wave == 0 && x == 0) {
-            float* pm = a.part_ml + (((size_t)t * a.H + h) * a.nsplit + split) * 2;
-            pm[0] = M * 0.69314718055994530942f;   // natural-log domain, as k_attn_combine expects
-            pm[1] = L;
-        }
-        const float invL = 1.0f / L;
-        for (int n = wave; n < NC; n += 4) {
-            float o = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; w++) o = fmaf(s_o[w][n][lane][rr], f[w], o);
-            const int d = 16 * n + x;
-            if (a.nsplit > 1) {
-                a.part_acc[(((size_t)t * a.H + h) * a.nsplit + split) * HD + d] = o;
-                continue;
-            }
-            o *= invL;
-            if (a.out_f32) a.out_f32[((size_t)t * a.H + h) * HD + d] = o;
-            if (a.out_a16) {
-                const int kk = h * HD + d;
-                const float xv = fminf(fmaxf(o, -65504.f), 65504.f);
-                const __half hi = __float2half_rn(xv);
-                const __half lo = __float2half_rn(xv - __half2float(hi));
-                const size_t tl = ((size_t)(t >> 4) * a.Kb_out + (kk >> 5)) * 2;
-                const size_t off = (size_t)((t & 15) + 16 * ((kk >> 3) & 3)) * 8 + (kk & 7);
-                a.out_a16[tl * TILE_HALVES + off] = hi;
-                a.out_a16[(tl + 1) * TILE_HALVES + off] = lo;
-            }
-        }
+        w.finish_solo();
+    } else {
+        __shared__ __attribute__((aligned(16))) unsigned char s_merge[attn16_lds<HD>()];
+        w.deposit(s_merge, wave);
+        __syncthreads();
+        w.merge(s_merge, wave);
     }
 }
 

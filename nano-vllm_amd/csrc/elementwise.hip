@@ -82,8 +82,12 @@ __global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, _
                                                         float* __restrict__ ss, const __half* __restrict__ table,
                                                         const int* __restrict__ tokens,
                                                         const float* __restrict__ gain, int D, int ss_tiles,
-                                                        const int* __restrict__ tok_src, const int* __restrict__ prev) {
+                                                        const int* __restrict__ tok_src, const int* __restrict__ prev,
+                                                        unsigned* __restrict__ zero, int n_zero, unsigned* __restrict__ zero_word) {
     const int t = blockIdx.x;
+    // words the next launch expects to find zero (arrival counters of the decode chain)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = 0u;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
     // a token the host has not seen yet: the arg-max the previous pass left in HBM
     const int tok = (tok_src && tok_src[t] >= 0) ? prev[tok_src[t]] : tokens[t];
     const __half* row = table + (size_t)tok * D;
@@ -111,12 +115,13 @@ __global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, _
 }
 
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
-                           const float* gain, int T, int D, const int* tok_src, const int* prev) {
+                           const float* gain, int T, int D, const int* tok_src, const int* prev, unsigned* zero, int n_zero,
+                           unsigned* zero_word) {
     if (T <= 0) return;
     if (D % 32) NVLLM_FATAL("embedding width %d is not a multiple of 32", D);
     ProfScope ps(PC_EMBED, (double)T * D * 10, 0);
     NVLLM_LAUNCH(k_embed_prescale, dim3(T), dim3(256), 0, x, a16, ss, table, tokens, gain, D,
-                       cdiv(D, 32), tok_src, prev);
+                       cdiv(D, 32), tok_src, prev, zero, n_zero, zero_word);
 }
 
 // Residual add + preparation of the next projection's input, for a projection whose

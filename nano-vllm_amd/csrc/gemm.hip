@@ -38,373 +38,24 @@
 // the projection).
 #include <vector>
 
-#include "gemm_common.h"
+#include "gemm_tile.h"
 
 namespace nvllm {
 
-// Weight tiles are read once per launch: non-temporal loads (a build knob for A/B runs)
-#ifdef NVLLM_W_PLAIN
-#define NVLLM_WLOAD(p) (*(p))
-#else
-#define NVLLM_WLOAD(p) __builtin_nontemporal_load(p)
-#endif
-
-template <int NBW, int TB, int NW, int EPI, typename KVT>
-__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
-    static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
 #ifndef NVLLM_RW
 #define NVLLM_RW 4
 #endif
 #ifndef NVLLM_RA
 #define NVLLM_RA 2
 #endif
-    constexpr int RW = NVLLM_RW;       // weight ring depth (K-steps in flight)
-    constexpr int RA = NVLLM_RA;       // activation ring depth
-    constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
-    constexpr int ITEMS = 2 * TB * 64; // float4 results per round
-    constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
-    // the waves' partial tiles, all row blocks at once: red[wave][row block][token block][lane]
+
+// One workgroup = one tile (gemm_tile.h); weight ring of NVLLM_RW K-steps, activation ring of NVLLM_RA.
+template <int NBW, int TB, int NW, int EPI, typename KVT>
+__global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    typedef f4_t RedTile[NBW][TB][64];
-    RedTile* red = reinterpret_cast<RedTile*>(lds_dyn);
-    __shared__ float s_rinv[TB * 16];
-    __shared__ float s_part[(NW * 64) / (TB * 16)][TB * 16];
-    __shared__ float s_ss[2][TB * 16];
-    __shared__ unsigned s_ticket;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nb0 = blockIdx.x * NBW;
-    if (nb0 >= p.NB) return;   // grid padded for XCD alignment
-    NVLLM_STAMP(0, lane);
-    const int kb_begin = blockIdx.y * p.kb_per_split;
-    const int kb_end = min(p.Kb, kb_begin + p.kb_per_split);
-    const int tb0 = blockIdx.z * TB;
-    const int first = kb_begin + wave;
-    const int nsteps = first < kb_end ? (kb_end - first + NW - 1) / NW : 0;
-    const h8_t* wp[NBW];
-#pragma unroll
-    for (int i = 0; i < NBW; i++)
-        wp[i] = reinterpret_cast<const h8_t*>(p.W + (size_t)min(nb0 + i, p.NB - 1) * p.nb_stride) + lane;
-    const h8_t* ap[TB];
-#pragma unroll
-    for (int j = 0; j < TB; j++)
-        ap[j] = reinterpret_cast<const h8_t*>(p.A + (size_t)min(tb0 + j, p.Tb - 1) * p.Kb * 2 * TILE_HALVES) + lane;
-
-    f4_t acc[NBW][TB];
-#pragma unroll
-    for (int i = 0; i < NBW; i++)
-#pragma unroll
-        for (int j = 0; j < TB; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-    h8_t w[RW][NBW];
-    h8_t ah[RA][TB], al[RA][TB];
-    auto kb_of = [&](int s) { return first + NW * s; };
-
-    // Loads are issued only for steps that exist (wave-uniform branches): a clamped
-    // re-load of the last tile would be real HBM traffic, since streamed weights are
-    // loaded non-temporally and do not stay in L2.
-#pragma unroll
-    for (int s = 0; s < RW; s++)
-        if (s < nsteps) {
-            const int kb = kb_of(s);
-#pragma unroll
-            for (int i = 0; i < NBW; i++) w[s][i] = NVLLM_WLOAD(wp[i] + (size_t)kb * 64);
-        }
-#pragma unroll
-    for (int s = 0; s < RA; s++)
-        if (s < nsteps) {
-            const int kb = kb_of(s);
-#pragma unroll
-            for (int j = 0; j < TB; j++) {
-                ah[s][j] = ap[j][(size_t)kb * 128];
-                al[s][j] = ap[j][(size_t)kb * 128 + 64];
-            }
-        }
-    // 1/rms of this token group, from the producer's per-tile sums of squares: every
-    // thread sums a slice of one token's tiles (independent loads, issued while the
-    // first weight tiles are in flight); the slices meet in LDS before the epilogue.
-    if (p.e.ss_in != nullptr) {
-        constexpr int PARTS = (NW * 64) / (TB * 16);
-        const int tl = threadIdx.x % (TB * 16), part = threadIdx.x / (TB * 16);
-        const int t = min(tb0 * 16 + tl, p.T - 1);
-        const int src = p.e.ss_gather ? p.e.ss_gather[t] : t;
-        const float* sp = p.e.ss_in + (size_t)src * p.e.ss_tiles;
-        float ss = 0.f;
-        for (int j = part; j < p.e.ss_tiles; j += PARTS) ss += sp[j];
-        s_part[part][tl] = ss;
-    }
-    NVLLM_STAMP(1, lane);
-    for (int s0 = 0; s0 < nsteps; s0 += RW) {
-#pragma unroll
-        for (int r = 0; r < RW; r++) {
-            const int s = s0 + r;
-            if (s < nsteps) {
-#pragma unroll
-                for (int i = 0; i < NBW; i++)
-#pragma unroll
-                    for (int j = 0; j < TB; j++) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
-                    }
-                if (s == 0) NVLLM_STAMP(2, acc[NBW - 1][TB - 1][0]);
-                if (s + RW < nsteps) {
-                    const int kbw = kb_of(s + RW);
-#pragma unroll
-                    for (int i = 0; i < NBW; i++) w[r][i] = NVLLM_WLOAD(wp[i] + (size_t)kbw * 64);
-                }
-                if (s + RA < nsteps) {
-                    const int kba = kb_of(s + RA);
-#pragma unroll
-                    for (int j = 0; j < TB; j++) {
-                        ah[r % RA][j] = ap[j][(size_t)kba * 128];
-                        al[r % RA][j] = ap[j][(size_t)kba * 128 + 64];
-                    }
-                }
-            }
-        }
-    }
-    NVLLM_STAMP(3, acc[NBW - 1][TB - 1][0]);
-    // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
-    // so that they travel while the K split is being closed (every workgroup does it;
-    // only the one that ends up running the epilogue uses them).  Indices are clamped,
-    // not predicated: unconditional loads.
-    const GemmEpilogue& ep = p.e;
-    float4 pf_x[ROUNDS][IPT], pf_g[ROUNDS][IPT];
-    int pf_pos = 0, pf_row = -1;
-    if (EPI == GemmEpilogue::RESID_A16) {
-#pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = min((int)threadIdx.x + q * NW * 64, ITEMS - 1);
-                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                const int t = min(tb0 * 16 + j * 16 + (l & 15), p.T - 1);
-                const int n = min((nb0 + 2 * h + i) * 16 + 4 * (l >> 4), p.N - 4);
-                pf_x[h][q] = *reinterpret_cast<const float4*>(ep.x + (size_t)t * p.N + n);
-                pf_g[h][q] = *reinterpret_cast<const float4*>(ep.gain_next + n);
-            }
-    }
-    if (EPI == GemmEpilogue::ROPE_KV) {   // all items of a thread belong to one token
-        const int e = min((int)threadIdx.x, ITEMS - 1);
-        const int t = min(tb0 * 16 + ((e >> 6) % TB) * 16 + (e & 15), p.T - 1);
-        pf_pos = ep.pos[t];
-        pf_row = ep.kv_row[t];
-    }
-    // ---- 1. sum the waves' partial tiles through LDS: every wave stores all its tiles, ONE
-    // barrier, then thread `e` (item e = threadIdx.x + q * NW*64) collects, per round h (two row
-    // blocks), the float4 for token t(e) and features n(h, e) .. n+3, in wave order.
-    f4_t v[ROUNDS][IPT];
-#pragma unroll
-    for (int i = 0; i < NBW; i++)
-#pragma unroll
-        for (int j = 0; j < TB; j++) red[wave][i][j][lane] = acc[i][j];
-    __syncthreads();
-    if (ep.ss_in != nullptr && threadIdx.x < TB * 16) {
-        // 1/rms per token from the slices gathered at the top (s_part: visible since the barrier
-        // above; s_rinv is read by the epilogue after at least one more barrier)
-        constexpr int PARTS = (NW * 64) / (TB * 16);
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < PARTS; q++) ss += s_part[q][threadIdx.x];
-        s_rinv[threadIdx.x] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
-    }
-#pragma unroll
-    for (int h = 0; h < ROUNDS; h++) {
-#pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            const int e = threadIdx.x + q * NW * 64;
-            f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
-            if (e < ITEMS) {
-                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                sum = red[0][2 * h + i][j][l];
-#pragma unroll
-                for (int wv = 1; wv < NW; wv++) sum += red[wv][2 * h + i][j][l];
-            }
-            v[h][q] = sum;
-        }
-    }
-    __syncthreads();   // everybody has read the partial tiles (the epilogue reuses the array) and s_rinv is visible
-    NVLLM_STAMP(4, v[ROUNDS - 1][IPT - 1][0]);
-    // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
-    const unsigned tile_id = blockIdx.z * gridDim.x + blockIdx.x;
-    if (p.ksplit > 1) {
-        float* my = p.slab + ((size_t)tile_id * p.ksplit + blockIdx.y) * (ROUNDS * ITEMS * 4);
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, ROUNDS * ITEMS * 16, 0x00020000);
-#pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = threadIdx.x + q * NW * 64;
-                if (e < ITEMS)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[h][q]), rs, (h * ITEMS + e) * 16, 0,
-                                                           /*sc1: write through*/ 16);
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (s_ticket != (unsigned)p.ksplit - 1) return;     // not the last slice of this tile
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
-        __syncthreads();
-        const float* base = p.slab + (size_t)tile_id * p.ksplit * (ROUNDS * ITEMS * 4);
-        // Every slab load of both rounds is issued before the first add: one round trip.
-        // Slice indices past the end are clamped (a repeated load), not predicated, so the
-        // loads stay unconditional; sums are taken in slice order.
-#pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) v[h][q] = f4_t{0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
-            f4_t part[ROUNDS][IPT][8];
-#pragma unroll
-            for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-                for (int q = 0; q < IPT; q++) {
-                    const int e = min((int)threadIdx.x + q * NW * 64, ITEMS - 1);
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int sl = min(s0 + u, p.ksplit - 1);
-                        part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
-                    }
-                }
-#pragma unroll
-            for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-                for (int q = 0; q < IPT; q++)
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (s0 + u < p.ksplit) v[h][q] += part[h][q][u];
-        }
-        // ready for the next launch (nobody else touches this tile's counter any more)
-        if (threadIdx.x == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    NVLLM_STAMP(5, v[ROUNDS - 1][IPT - 1][0]);
-    // ---- 3. epilogue on complete sums
-    float ssq[ROUNDS][IPT];
-#pragma unroll
-    for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-        for (int q = 0; q < IPT; q++) ssq[h][q] = 0.f;
-#pragma unroll
-    for (int h = 0; h < ROUNDS; h++) {
-        if (EPI == GemmEpilogue::SWIGLU_A16) {
-            // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads:
-            // swap through LDS so that the i = 0 thread has both
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = threadIdx.x + q * NW * 64;
-                if (e < ITEMS) red[0][(e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            const int e = threadIdx.x + q * NW * 64;
-            if (e >= ITEMS) continue;
-            const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-            const int tl = j * 16 + (l & 15);
-            const int t = tb0 * 16 + tl;
-            const int nb = nb0 + 2 * h + i;
-            const int n = nb * 16 + 4 * (l >> 4);
-            const bool live = t < p.T && tb0 + j < p.Tb && nb < p.NB;
-            const float rinv = ep.ss_in ? s_rinv[tl] : 1.0f;
-            float y[4] = {v[h][q][0] * rinv, v[h][q][1] * rinv, v[h][q][2] * rinv, v[h][q][3] * rinv};
-            if (EPI == GemmEpilogue::F32) {
-                if (live) {
-                    float* o = ep.out + (size_t)t * ep.ldo + n;
-                    if (n + 3 < p.N && (ep.ldo & 3) == 0) {
-                        *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            if (n + r < p.N) o[r] = y[r];
-                    }
-                }
-            } else if (EPI == GemmEpilogue::SWIGLU_A16) {
-                if (i == 0 && live) {
-                    const f4_t u = red[0][1][j][l];
-                    float z[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], u[r] * rinv);
-                    const int hid = (nb >> 1) * 16 + 4 * (l >> 4);
-                    store_a16_4(ep.a16_out, ep.Kb_out, t, hid, z);
-                }
-            } else if (EPI == GemmEpilogue::RESID_A16) {
-                if (live) {
-                    float* xr = ep.x + (size_t)t * p.N + n;
-                    const float4 xo = pf_x[h][q];
-                    const float4 g = pf_g[h][q];
-                    // residual add as the reference's accum(): x = x + branch (layers.c:163-168)
-                    const float xn[4] = {__fadd_rn(xo.x, y[0]), __fadd_rn(xo.y, y[1]), __fadd_rn(xo.z, y[2]), __fadd_rn(xo.w, y[3])};
-                    *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
-                    const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
-                    store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
-                    ssq[h][q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
-                }
-            } else {  // ROPE_KV
-                if (live) {
-                    if (n < ep.QD + ep.KD) {   // q or k: rotate the two pairs of this float4 (layers.c:118-141)
-                        const int d = (n < ep.QD ? n : n - ep.QD) % ep.hd;
-                        const float2* tab = ep.rope + (size_t)pf_pos * (ep.hd >> 1) + (d >> 1);
-                        const float2 c0 = tab[0], c1 = tab[1];
-                        const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
-                        y[0] = __fsub_rn(__fmul_rn(a0, c0.x), __fmul_rn(b0, c0.y));
-                        y[1] = __fadd_rn(__fmul_rn(a0, c0.y), __fmul_rn(b0, c0.x));
-                        y[2] = __fsub_rn(__fmul_rn(a1, c1.x), __fmul_rn(b1, c1.y));
-                        y[3] = __fadd_rn(__fmul_rn(a1, c1.y), __fmul_rn(b1, c1.x));
-                    }
-                    if (n < ep.QD) {
-                        *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
-                    } else if (pf_row >= 0) {
-                        const long block = pf_row / ep.bs;
-                        const int key = pf_row % ep.bs;
-                        const bool is_k = n < ep.QD + ep.KD;
-                        const int c = is_k ? n - ep.QD : n - ep.QD - ep.KD;
-                        KVT* pool = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off;
-                        if (sizeof(KVT) == 4) {   // the reference's rows (memory.c:37-43)
-                            kv_put4<KVT>(pool + (block * ep.bs + key) * ep.KD + c, y);
-                        } else {                  // fp16 pages in matrix-core operand order
-                            const int kvh = c / ep.hd, d = c % ep.hd;
-                            KVT* page = pool + kv16_page(block, kvh, ep.KD / ep.hd, ep.hd);
-                            if (is_k) kv_put4<KVT>(page + kv16_k_off(key, d), y);
-                            else kv_put4_strided<KVT>(page + kv16_v_off(key, d), y);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (EPI == GemmEpilogue::RESID_A16) {
-        // per-token sum of x^2 over each 32-feature group (= one round: two row blocks):
-        // over the 4 lane groups (l>>4), then over the round's two row blocks (i)
-        const int ss_cols = (p.N + 31) >> 5;
-#pragma unroll
-        for (int h = 0; h < ROUNDS; h++) {
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                float sq = ssq[h][q];
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                const int e = threadIdx.x + q * NW * 64;
-                if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
-            }
-            __syncthreads();
-            if (threadIdx.x < TB * 16) {
-                const int t = tb0 * 16 + threadIdx.x;
-                const int col = blockIdx.x * ROUNDS + h;
-                if (t < p.T && col < ss_cols) ep.ss_out[(size_t)t * ss_cols + col] = s_ss[0][threadIdx.x] + s_ss[1][threadIdx.x];
-            }
-        }
-    }
-#ifdef NVLLM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores issued so far have left the CU
-#endif
-    NVLLM_STAMP(6, ssq[0][0]);
+    h8_t w[NVLLM_RW][NBW];
+    const TileIdx ix{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x};
+    gemm_tile<NBW, TB, NW, NVLLM_RW, NVLLM_RA, EPI, KVT, false, false>(p, ix, lds_dyn, w, [] {}, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ launch
@@ -446,8 +97,8 @@ constexpr int MAX_COUNTERS = 1 << 16;
 // token block); sizes beyond the 64 KiB default are enabled once.
 template <int NBW, int TB, int NW, int EPI, typename KVT>
 static void launch_k(const GemmArgs& a, dim3 grid) {
-    constexpr int shmem = NW * NBW * TB * 64 * 16;
-    static_assert(shmem <= 144 * 1024, "partial tiles must fit the CU's LDS next to the static arrays");
+    constexpr int shmem = gemm_tile_lds<NBW, TB, NW>();
+    static_assert(shmem <= 160 * 1024, "partial tiles must fit the CU's LDS");
     static bool enabled = false;
     if (shmem > 64 * 1024 && !enabled) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<NBW, TB, NW, EPI, KVT>),
@@ -467,15 +118,83 @@ static void launch_tb(const GemmArgs& a, dim3 grid) {
     }
 }
 
+// The decomposition of a decode-sized projection (T below the dense-tile threshold): row blocks per
+// tile, token blocks per group, K slices, and the grid they make.  `slab_cap` > 0: a caller's slab of
+// that many bytes (a split whose partial tiles do not fit it is not taken).
+GemmPlan gemm_plan(int N, int K, int T, int epi_kind, int force_ksplit, long max_counters, size_t slab_cap) {
+    const int NB = cdiv(N, 16), Kb = cdiv(K, 32), Tb = cdiv(T, 16);
+    int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
+    int nbw = GEMM_NBW;
+    int ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, K, T);
+    // Narrow projections with a short K (wo, qkv at decode): instead of cutting K across
+    // workgroups -- whose partial sums then meet through memory, a chain of dependent
+    // round trips -- cut the TOKENS: 32-feature tiles x 16-token groups, every workgroup
+    // sweeps the whole K and finishes its own outputs.  The weight tile is read by the
+    // token groups' workgroups (one read from HBM, the rest from cache); worth it while a
+    // full sweep is short.
+    static const int tsplit_env = getenv("NVLLM_GEMM_TSPLIT") ? atoi(getenv("NVLLM_GEMM_TSPLIT")) : 1;
+    const bool tsplit = tsplit_env && force_ksplit <= 0 && ks > 1 && TB > 1 && Kb <= 64 && Tb <= 8 &&
+                        epi_kind != GemmEpilogue::SWIGLU_A16;
+    if (tsplit) {
+        // 16-token groups unless that makes more workgroups than CUs (a CU with two of
+        // them takes twice as long: measured 12.3 us against 10.0 for qkv); then 32-token groups
+        const bool wide = cdiv(NB, 2) * Tb > rt().num_cus;
+        TB = wide ? 2 : 1;
+        nbw = 2;
+        ks = 1;
+    }
+    // Long-K projections that still need a K split (w_down): half the split, two 32-token
+    // groups -- the same number of workgroups, but each tile's reduction reads half as
+    // many, half as large partials (measured 14.9 -> 13.8 us; more workgroups than CUs,
+    // or a shallower split, measured slower).
+    if (!tsplit && force_ksplit <= 0 && TB == 4 && ks >= 4 && ks % 2 == 0 && Tb <= 4) {
+        TB = 2;
+        ks /= 2;
+    }
+    // The wide gate/up projection at full decode width: 64 x 64 tiles give 176 workgroups
+    // (80 CUs idle) pulling 768 KiB each; 96-feature x 32-token tiles give 236 workgroups
+    // pulling 640 KiB each, still in one wave of workgroups.
+    static const int gu_env = getenv("NVLLM_GEMM_GU96") ? atoi(getenv("NVLLM_GEMM_GU96")) : 1;
+    const bool gu96 = gu_env && !tsplit && force_ksplit <= 0 && epi_kind == GemmEpilogue::SWIGLU_A16 && ks == 1 &&
+                      Tb > 2 && Tb <= 4 && cdiv(NB, 6) * 2 <= rt().num_cus && cdiv(NB, 4) < rt().num_cus;
+    if (gu96) {
+        TB = 2;
+        nbw = 6;
+    }
+    int tiles_n = cdiv(NB, nbw);
+    const int tiles_t = cdiv(Tb, TB);
+    // Token groups of one tile read the same weights: with workgroups dealt round-robin to
+    // the 8 XCDs, a grid width that is a multiple of 8 puts them behind the same L2 (speed
+    // only; surplus workgroups exit at once).
+    if (tiles_t > 1 && ks == 1) tiles_n = (tiles_n + 7) & ~7;
+    if ((long)tiles_n * tiles_t > max_counters) ks = 1;
+    int kb_per_split = cdiv(Kb, ks);
+    ks = cdiv(Kb, kb_per_split);
+    const size_t slab_tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
+    // a caller's slab that cannot hold the partial tiles: every workgroup sweeps the whole K instead
+    if (slab_cap > 0 && ks > 1 && (size_t)tiles_n * tiles_t * ks * slab_tile_bytes > slab_cap) {
+        ks = 1;
+        kb_per_split = Kb;
+    }
+    GemmPlan pl;
+    pl.nbw = nbw;
+    pl.TB = TB;
+    pl.ks = ks;
+    pl.kb_per_split = kb_per_split;
+    pl.tiles_n = tiles_n;
+    pl.tiles_t = tiles_t;
+    // more tiles than CUs without a K split (the classifier): four waves per workgroup, so that two
+    // workgroups share a CU and one's start-up overlaps the other's streaming (41 -> 35.5 us)
+    pl.nw = (epi_kind == GemmEpilogue::F32 && nbw == GEMM_NBW && TB == 4 && ks == 1 && (long)tiles_n * tiles_t > rt().num_cus) ? 4 : GEMM_NW;
+    return pl;
+}
+
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
                 const GemmEpilogue& epi, int force_ksplit, int prof_cls, const GemmWorkspace* wsp) {
     if (T <= 0 || N <= 0) return 1;
     ensure_init();
     // the caller's workspace (counters already zero), or the library's own grow-only buffers
-    if (!wsp && !g_counters) {
-        HIP_CHECK(hipMalloc((void**)&g_counters, MAX_COUNTERS * sizeof(unsigned)));
-        HIP_CHECK(hipMemsetAsync(g_counters, 0, MAX_COUNTERS * sizeof(unsigned), rt().stream));
-    }
+    if (!wsp) gemm_tile_counters();
     const long max_counters = wsp ? wsp->n_counters : MAX_COUNTERS;
     GemmArgs a;
     a.W = tiles;
@@ -527,59 +246,11 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         launch_gemm_prefill(a);
         return a.ksplit;
     }
-    int TB = T <= 16 ? 1 : (T <= 32 ? 2 : 4);
-    int nbw = GEMM_NBW;
-    int ks = force_ksplit > 0 ? force_ksplit : gemm_pick_ksplit(N, w.K, T);
-    // Narrow projections with a short K (wo, qkv at decode): instead of cutting K across
-    // workgroups -- whose partial sums then meet through memory, a chain of dependent
-    // round trips -- cut the TOKENS: 32-feature tiles x 16-token groups, every workgroup
-    // sweeps the whole K and finishes its own outputs.  The weight tile is read by the
-    // token groups' workgroups (one read from HBM, the rest from cache); worth it while a
-    // full sweep is short.
-    static const int tsplit_env = getenv("NVLLM_GEMM_TSPLIT") ? atoi(getenv("NVLLM_GEMM_TSPLIT")) : 1;
-    const bool tsplit = tsplit_env && force_ksplit <= 0 && ks > 1 && TB > 1 && a.Kb <= 64 && a.Tb <= 8 &&
-                        epi.kind != GemmEpilogue::SWIGLU_A16;
-    if (tsplit) {
-        // 16-token groups unless that makes more workgroups than CUs (a CU with two of
-        // them takes twice as long: measured 12.3 us against 10.0 for qkv); then 32-token groups
-        const bool wide = cdiv(a.NB, 2) * a.Tb > rt().num_cus;
-        TB = wide ? 2 : 1;
-        nbw = 2;
-        ks = 1;
-    }
-    // Long-K projections that still need a K split (w_down): half the split, two 32-token
-    // groups -- the same number of workgroups, but each tile's reduction reads half as
-    // many, half as large partials (measured 14.9 -> 13.8 us; more workgroups than CUs,
-    // or a shallower split, measured slower).
-    if (!tsplit && force_ksplit <= 0 && TB == 4 && ks >= 4 && ks % 2 == 0 && a.Tb <= 4) {
-        TB = 2;
-        ks /= 2;
-    }
-    // The wide gate/up projection at full decode width: 64 x 64 tiles give 176 workgroups
-    // (80 CUs idle) pulling 768 KiB each; 96-feature x 32-token tiles give 236 workgroups
-    // pulling 640 KiB each, still in one wave of workgroups.
-    static const int gu_env = getenv("NVLLM_GEMM_GU96") ? atoi(getenv("NVLLM_GEMM_GU96")) : 1;
-    const bool gu96 = gu_env && !tsplit && force_ksplit <= 0 && epi.kind == GemmEpilogue::SWIGLU_A16 && ks == 1 &&
-                      a.Tb > 2 && a.Tb <= 4 && cdiv(a.NB, 6) * 2 <= rt().num_cus && cdiv(a.NB, 4) < rt().num_cus;
-    if (gu96) {
-        TB = 2;
-        nbw = 6;
-    }
-    int tiles_n = cdiv(a.NB, nbw);
-    const int tiles_t = cdiv(a.Tb, TB);
-    // Token groups of one tile read the same weights: with workgroups dealt round-robin to
-    // the 8 XCDs, a grid width that is a multiple of 8 puts them behind the same L2 (speed
-    // only; surplus workgroups exit at once).
-    if (tiles_t > 1 && ks == 1) tiles_n = (tiles_n + 7) & ~7;
-    if ((long)tiles_n * tiles_t > max_counters) ks = 1;
-    a.kb_per_split = cdiv(a.Kb, ks);
-    ks = cdiv(a.Kb, a.kb_per_split);
+    const GemmPlan pl = gemm_plan(N, w.K, T, epi.kind, force_ksplit, max_counters, wsp ? wsp->slab_bytes : 0);
+    const int TB = pl.TB, nbw = pl.nbw, tiles_n = pl.tiles_n, tiles_t = pl.tiles_t;
+    int ks = pl.ks;
+    a.kb_per_split = pl.kb_per_split;
     const size_t slab_tile_bytes = (size_t)(nbw / 2) * 2 * TB * 64 * 16;
-    // a caller's slab that cannot hold the partial tiles: every workgroup sweeps the whole K instead
-    if (wsp && ks > 1 && (size_t)tiles_n * tiles_t * ks * slab_tile_bytes > wsp->slab_bytes) {
-        ks = 1;
-        a.kb_per_split = a.Kb;
-    }
     a.ksplit = ks;
     a.counters = wsp ? wsp->counters : g_counters;
 #ifdef NVLLM_STAMPS
@@ -602,9 +273,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     } else if (nbw == 2) {   // token-split configuration
         if (kv16) { if (TB == 1) launch_tb<2, 1, __half>(a, grid); else launch_tb<2, 2, __half>(a, grid); }
         else { if (TB == 1) launch_tb<2, 1, float>(a, grid); else launch_tb<2, 2, float>(a, grid); }
-    } else if (epi.kind == GemmEpilogue::F32 && TB == 4 && ks == 1 && (long)tiles_n * tiles_t > rt().num_cus) {
-        // more tiles than CUs (the classifier): four waves per workgroup, so that two
-        // workgroups share a CU and one's start-up overlaps the other's streaming (41 -> 35.5 us)
+    } else if (pl.nw == 4) {   // the classifier's four-wave form
         launch_k<GEMM_NBW, 4, 4, GemmEpilogue::F32, float>(a, grid);
     } else if (kv16) {
         if (TB == 1) launch_tb<GEMM_NBW, 1, __half>(a, grid);
@@ -616,6 +285,14 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         else launch_tb<GEMM_NBW, 4, float>(a, grid);
     }
     return ks;
+}
+
+unsigned* gemm_tile_counters() {
+    if (!g_counters) {
+        HIP_CHECK(hipMalloc((void**)&g_counters, MAX_COUNTERS * sizeof(unsigned)));
+        HIP_CHECK(hipMemsetAsync(g_counters, 0, MAX_COUNTERS * sizeof(unsigned), rt().stream));
+    }
+    return g_counters;
 }
 
 void gemm_release() {

@@ -38,8 +38,16 @@ struct GemmArgs {
         if (p.stamps && threadIdx.x == 0)                                                                     \
             p.stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = t__; \
     } while (0)
+// the same inside gemm_tile(), whose caller says where the tile's eight readings go (`stamps_wg`)
+#define NVLLM_TSTAMP(k, dep)                                                                        \
+    do {                                                                                            \
+        unsigned long long t__;                                                                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) : "v"(dep) : "memory");  \
+        if (stamps_wg && tid == 0) stamps_wg[(k)] = t__;                                    \
+    } while (0)
 #else
 #define NVLLM_STAMP(k, dep) do {} while (0)
+#define NVLLM_TSTAMP(k, dep) do {} while (0)
 #endif
 
 __device__ __forceinline__ float silu_mul(float g, float u) {

@@ -1,0 +1,520 @@
+// gemm_tile.h -- one output tile of a decode-sized projection as a device function: what a
+// workgroup of the projection kernel does (gemm.hip describes the decomposition and the
+// epilogues).  Two callers:
+//   k_gemm           one launch per projection; operands written by earlier launches (COH = false)
+//   k_decode_chain   every projection and attention of a decode step in ONE launch; a tile's
+//                    activations were written by other workgroups of the same launch (COH = true)
+//
+// COH = true changes how bytes that another workgroup of the SAME launch wrote or will read move:
+// every such store is write-through (sc1) and every such load bypasses this CU's vector cache
+// (sc1), so that the caller can hand tiles over with a drained counter add on the producer and a
+// relaxed poll on the consumer, without cache write-backs or invalidates.  Weights, gains, RoPE
+// angles and the integer arrays of the step are read-only during the launch and stay on plain loads.
+#pragma once
+
+#include "gemm_common.h"
+
+namespace nvllm {
+
+// Weight tiles are read once per launch: non-temporal loads (a build knob for A/B runs)
+#ifdef NVLLM_W_PLAIN
+#define NVLLM_WLOAD(p) (*(p))
+#else
+#define NVLLM_WLOAD(p) __builtin_nontemporal_load(p)
+#endif
+
+constexpr int AUX_SC1 = 16;   // cache-policy bits of the raw buffer builtins on gfx950: bit 4 = sc1
+
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+// position of a tile in its projection's grid (what blockIdx / gridDim are to k_gemm)
+struct TileIdx {
+    int x, y, z;   // feature tile, K slice, token group
+    int gx;        // feature tiles per token group (grid width, padding included)
+};
+
+// bytes of dynamic LDS a tile needs: the waves' partial tiles, then four small arrays
+template <int NBW, int TB, int NW>
+constexpr int gemm_tile_lds() {
+    return NW * NBW * TB * 64 * 16 + (TB * 16 + NW * 64 + 2 * TB * 16) * 4 + 16;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// 4 consecutive k of token t into hi/lo tiles with write-through stores (n % 4 == 0)
+__device__ __forceinline__ void store_a16_4_sc1(__half* a16, int Kb_out, int t, int n, const float* y) {
+    alignas(8) __half hi[4], lo[4];
+    split16_4(y, hi, lo);
+    const size_t tile = ((size_t)(t >> 4) * Kb_out + (n >> 5)) * 2;
+    const size_t off = (size_t)((t & 15) + 16 * ((n >> 3) & 3)) * 8 + (n & 7);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(a16 + tile * TILE_HALVES + off),
+                       *reinterpret_cast<unsigned long long*>(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(a16 + (tile + 1) * TILE_HALVES + off),
+                       *reinterpret_cast<unsigned long long*>(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename KVT>
+__device__ __forceinline__ void kv_put4_sc1(KVT* dst, const float* y);
+template <>
+__device__ __forceinline__ void kv_put4_sc1<float>(float* dst, const float* y) {
+    alignas(8) float a[2] = {y[0], y[1]}, b[2] = {y[2], y[3]};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), *reinterpret_cast<unsigned long long*>(a),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + 2), *reinterpret_cast<unsigned long long*>(b),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <>
+__device__ __forceinline__ void kv_put4_sc1<__half>(__half* dst, const float* y) {
+    alignas(8) __half h[4] = {kv_sat_half(y[0]), kv_sat_half(y[1]), kv_sat_half(y[2]), kv_sat_half(y[3])};
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), *reinterpret_cast<unsigned long long*>(h),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename KVT>
+__device__ __forceinline__ void kv_put4_strided_sc1(KVT* dst, const float* y);
+template <>
+__device__ __forceinline__ void kv_put4_strided_sc1<float>(float*, const float*) {}
+template <>
+__device__ __forceinline__ void kv_put4_strided_sc1<__half>(__half* dst, const float* y) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const __half h = kv_sat_half(y[e]);
+        __hip_atomic_store(reinterpret_cast<unsigned short*>(dst + 4 * e), *reinterpret_cast<const unsigned short*>(&h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The first RW K-steps of a wave's weight stream: they depend on nothing the step computes, so a
+// caller that knows its next tile may issue them long before that tile's activations exist.
+// Must be followed by gemm_tile<..., PRE = true> with the same arguments.
+// `tid` = threadIdx.x (a caller that runs many tiles in a loop passes it through an opaque copy, so that
+// the compiler does not hoist every tile's per-lane index arithmetic out of that loop and keep it in registers).
+template <int NBW, int NW, int RW>
+__device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const TileIdx ix, h8_t (&w)[RW][NBW], const int tid, const bool on = true) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb0 = ix.x * NBW;
+    const int kb_begin = ix.y * p.kb_per_split;
+    const int kb_end = min(p.Kb, kb_begin + p.kb_per_split);
+    const int first = kb_begin + wave;
+    // `on` = the workgroup has a tile at all; every ring entry is written either way (zeros where there
+    // is nothing to load), so that no entry carries a value over from an earlier use of the registers
+    const int nsteps = on && nb0 < p.NB && first < kb_end ? (kb_end - first + NW - 1) / NW : 0;
+    const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < RW; s++) {
+        if (s < nsteps) {
+            const int kb = first + NW * s;
+#pragma unroll
+            for (int i = 0; i < NBW; i++)
+                w[s][i] = NVLLM_WLOAD(reinterpret_cast<const h8_t*>(p.W + (size_t)min(nb0 + i, p.NB - 1) * p.nb_stride) + lane +
+                                      (size_t)kb * 64);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBW; i++) w[s][i] = zero;
+        }
+    }
+}
+
+// One tile.  Returns true when this workgroup wrote the tile's results (false: grid padding, or a
+// K slice that was not the last to arrive).  `after_loop()` runs once the K loop has consumed its
+// last operands and before the reduction and the epilogue: the place to start loads for later work.
+template <int NBW, int TB, int NW, int RW, int RA, int EPI, typename KVT, bool COH, bool PRE, typename Hook>
+__device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, unsigned char* lds_dyn, h8_t (&w)[RW][NBW],
+                                          Hook&& after_loop, const int tid) {
+    static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
+    static_assert(RW % RA == 0, "the activation ring must divide the weight ring");
+    constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
+    constexpr int ITEMS = 2 * TB * 64; // float4 results per round
+    constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
+    constexpr int PARTS = (NW * 64) / (TB * 16);
+    // the waves' partial tiles, all row blocks at once: red[wave][row block][token block][lane]
+    typedef f4_t RedTile[NBW][TB][64];
+    RedTile* red = reinterpret_cast<RedTile*>(lds_dyn);
+    float* s_rinv = reinterpret_cast<float*>(lds_dyn + NW * NBW * TB * 64 * 16);   // [TB * 16]
+    float (*s_part)[TB * 16] = reinterpret_cast<float (*)[TB * 16]>(s_rinv + TB * 16);   // [PARTS][TB * 16]
+    float (*s_ss)[TB * 16] = reinterpret_cast<float (*)[TB * 16]>(s_rinv + TB * 16 + NW * 64);   // [2][TB * 16]
+    unsigned* s_ticket = reinterpret_cast<unsigned*>(s_rinv + TB * 16 + NW * 64 + 2 * TB * 16);
+
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb0 = ix.x * NBW;
+    if (nb0 >= p.NB) {   // grid padded for XCD alignment
+        after_loop();
+        return false;
+    }
+#ifdef NVLLM_STAMPS
+    unsigned long long* const stamps_wg = p.stamps ? p.stamps + (size_t)((ix.z * p.ksplit + ix.y) * ix.gx + ix.x) * 8 : nullptr;
+#endif
+    NVLLM_TSTAMP(0, lane);
+    const int kb_begin = ix.y * p.kb_per_split;
+    const int kb_end = min(p.Kb, kb_begin + p.kb_per_split);
+    const int tb0 = ix.z * TB;
+    const int first = kb_begin + wave;
+    const int nsteps = first < kb_end ? (kb_end - first + NW - 1) / NW : 0;
+    const h8_t* wp[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; i++)
+        wp[i] = reinterpret_cast<const h8_t*>(p.W + (size_t)min(nb0 + i, p.NB - 1) * p.nb_stride) + lane;
+    // activations: pointers (plain loads), or byte offsets into a buffer descriptor (sc1 loads)
+    const h8_t* ap[TB];
+    int aoff[TB];
+    __amdgpu_buffer_rsrc_t rs_a = gemm_rsrc(p.A, (unsigned)p.Tb * (unsigned)p.Kb * 2048u);
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+        ap[j] = reinterpret_cast<const h8_t*>(p.A + (size_t)min(tb0 + j, p.Tb - 1) * p.Kb * 2 * TILE_HALVES) + lane;
+        aoff[j] = min(tb0 + j, p.Tb - 1) * p.Kb * 2048 + lane * 16;
+    }
+    auto load_act = [&](int j, int kb, h8_t& hi, h8_t& lo) {
+        if constexpr (COH) {
+            hi = __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[j], kb * 2048, AUX_SC1));
+            lo = __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[j] + 1024, kb * 2048, AUX_SC1));
+        } else {
+            hi = ap[j][(size_t)kb * 128];
+            lo = ap[j][(size_t)kb * 128 + 64];
+        }
+    };
+
+    f4_t acc[NBW][TB];
+#pragma unroll
+    for (int i = 0; i < NBW; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    h8_t ah[RA][TB], al[RA][TB];
+    auto kb_of = [&](int s) { return first + NW * s; };
+
+    // Loads are issued only for steps that exist (wave-uniform branches): a clamped
+    // re-load of the last tile would be real HBM traffic, since streamed weights are
+    // loaded non-temporally and do not stay in L2.
+    if constexpr (!PRE) {
+#pragma unroll
+        for (int s = 0; s < RW; s++)
+            if (s < nsteps) {
+                const int kb = kb_of(s);
+#pragma unroll
+                for (int i = 0; i < NBW; i++) w[s][i] = NVLLM_WLOAD(wp[i] + (size_t)kb * 64);
+            }
+    }
+#pragma unroll
+    for (int s = 0; s < RA; s++)
+        if (s < nsteps) {
+            const int kb = kb_of(s);
+#pragma unroll
+            for (int j = 0; j < TB; j++) load_act(j, kb, ah[s][j], al[s][j]);
+        }
+    // 1/rms of this token group, from the producer's per-tile sums of squares: every
+    // thread sums a slice of one token's tiles (independent loads, issued while the
+    // first weight tiles are in flight); the slices meet in LDS before the epilogue.
+    if (p.e.ss_in != nullptr) {
+        const int tl = tid % (TB * 16), part = tid / (TB * 16);
+        const int t = min(tb0 * 16 + tl, p.T - 1);
+        const int src = p.e.ss_gather ? p.e.ss_gather[t] : t;
+        const float* sp = p.e.ss_in + (size_t)src * p.e.ss_tiles;
+        float ss = 0.f;
+        if constexpr (COH) {
+            for (int j = part; j < p.e.ss_tiles; j += PARTS)
+                ss += __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(sp + j), __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+            for (int j = part; j < p.e.ss_tiles; j += PARTS) ss += sp[j];
+        }
+        s_part[part][tl] = ss;
+    }
+    NVLLM_TSTAMP(1, lane);
+    for (int s0 = 0; s0 < nsteps; s0 += RW) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const int s = s0 + r;
+            if (s < nsteps) {
+#pragma unroll
+                for (int i = 0; i < NBW; i++)
+#pragma unroll
+                    for (int j = 0; j < TB; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
+                    }
+                if (s == 0) NVLLM_TSTAMP(2, acc[NBW - 1][TB - 1][0]);
+                if (s + RW < nsteps) {
+                    const int kbw = kb_of(s + RW);
+#pragma unroll
+                    for (int i = 0; i < NBW; i++) w[r][i] = NVLLM_WLOAD(wp[i] + (size_t)kbw * 64);
+                }
+                if (s + RA < nsteps) {
+                    const int kba = kb_of(s + RA);
+#pragma unroll
+                    for (int j = 0; j < TB; j++) load_act(j, kba, ah[r % RA][j], al[r % RA][j]);
+                }
+            }
+        }
+    }
+    NVLLM_TSTAMP(3, acc[NBW - 1][TB - 1][0]);
+    after_loop();
+    // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
+    // so that they travel while the K split is being closed (every workgroup does it;
+    // only the one that ends up running the epilogue uses them).  Indices are clamped,
+    // not predicated: unconditional loads.
+    const GemmEpilogue& ep = p.e;
+    float4 pf_x[ROUNDS][IPT], pf_g[ROUNDS][IPT];
+    int pf_pos = 0, pf_row = -1;
+    __amdgpu_buffer_rsrc_t rs_x = gemm_rsrc(ep.x, (unsigned)p.T * (unsigned)p.N * 4u);
+    if (EPI == GemmEpilogue::RESID_A16) {
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = min(tid + q * NW * 64, ITEMS - 1);
+                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+                const int t = min(tb0 * 16 + j * 16 + (l & 15), p.T - 1);
+                const int n = min((nb0 + 2 * h + i) * 16 + 4 * (l >> 4), p.N - 4);
+                if constexpr (COH)
+                    pf_x[h][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (t * p.N + n) * 4, 0, AUX_SC1));
+                else
+                    pf_x[h][q] = *reinterpret_cast<const float4*>(ep.x + (size_t)t * p.N + n);
+                pf_g[h][q] = *reinterpret_cast<const float4*>(ep.gain_next + n);
+            }
+    }
+    if (EPI == GemmEpilogue::ROPE_KV) {   // all items of a thread belong to one token
+        const int e = min(tid, ITEMS - 1);
+        const int t = min(tb0 * 16 + ((e >> 6) % TB) * 16 + (e & 15), p.T - 1);
+        pf_pos = ep.pos[t];
+        pf_row = ep.kv_row[t];
+    }
+    // ---- 1. sum the waves' partial tiles through LDS: every wave stores all its tiles, ONE
+    // barrier, then thread `e` (item e = tid + q * NW*64) collects, per round h (two row
+    // blocks), the float4 for token t(e) and features n(h, e) .. n+3, in wave order.
+    f4_t v[ROUNDS][IPT];
+#pragma unroll
+    for (int i = 0; i < NBW; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++) red[wave][i][j][lane] = acc[i][j];
+    __syncthreads();
+    if (ep.ss_in != nullptr && tid < TB * 16) {
+        // 1/rms per token from the slices gathered at the top (s_part: visible since the barrier
+        // above; s_rinv is read by the epilogue after at least one more barrier)
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; q++) ss += s_part[q][tid];
+        s_rinv[tid] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
+    }
+#pragma unroll
+    for (int h = 0; h < ROUNDS; h++) {
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const int e = tid + q * NW * 64;
+            f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
+            if (e < ITEMS) {
+                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+                sum = red[0][2 * h + i][j][l];
+#pragma unroll
+                for (int wv = 1; wv < NW; wv++) sum += red[wv][2 * h + i][j][l];
+            }
+            v[h][q] = sum;
+        }
+    }
+    __syncthreads();   // everybody has read the partial tiles (the epilogue reuses the array) and s_rinv is visible
+    NVLLM_TSTAMP(4, v[ROUNDS - 1][IPT - 1][0]);
+    // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
+    const unsigned tile_id = ix.z * ix.gx + ix.x;
+    if (p.ksplit > 1) {
+        float* my = p.slab + ((size_t)tile_id * p.ksplit + ix.y) * (ROUNDS * ITEMS * 4);
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, ROUNDS * ITEMS * 16, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = tid + q * NW * 64;
+                if (e < ITEMS)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[h][q]), rs, (h * ITEMS + e) * 16, 0,
+                                                           /*sc1: write through*/ AUX_SC1);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0)
+            *s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*s_ticket != (unsigned)p.ksplit - 1) return false;     // not the last slice of this tile
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
+        __syncthreads();
+        const float* base = p.slab + (size_t)tile_id * p.ksplit * (ROUNDS * ITEMS * 4);
+        // Every slab load of both rounds is issued before the first add: one round trip.
+        // Slice indices past the end are clamped (a repeated load), not predicated, so the
+        // loads stay unconditional; sums are taken in slice order.
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+            for (int q = 0; q < IPT; q++) v[h][q] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
+            f4_t part[ROUNDS][IPT][8];
+#pragma unroll
+            for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+                for (int q = 0; q < IPT; q++) {
+                    const int e = min(tid + q * NW * 64, ITEMS - 1);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int sl = min(s0 + u, p.ksplit - 1);
+                        part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
+                    }
+                }
+#pragma unroll
+            for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+                for (int q = 0; q < IPT; q++)
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (s0 + u < p.ksplit) v[h][q] += part[h][q][u];
+        }
+        // ready for the next launch (nobody else touches this tile's counter any more)
+        if (tid == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    NVLLM_TSTAMP(5, v[ROUNDS - 1][IPT - 1][0]);
+    // ---- 3. epilogue on complete sums
+    float ssq[ROUNDS][IPT];
+#pragma unroll
+    for (int h = 0; h < ROUNDS; h++)
+#pragma unroll
+        for (int q = 0; q < IPT; q++) ssq[h][q] = 0.f;
+#pragma unroll
+    for (int h = 0; h < ROUNDS; h++) {
+        if (EPI == GemmEpilogue::SWIGLU_A16) {
+            // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads:
+            // swap through LDS so that the i = 0 thread has both
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                const int e = tid + q * NW * 64;
+                if (e < ITEMS) red[0][(e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < IPT; q++) {
+            const int e = tid + q * NW * 64;
+            if (e >= ITEMS) continue;
+            const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+            const int tl = j * 16 + (l & 15);
+            const int t = tb0 * 16 + tl;
+            const int nb = nb0 + 2 * h + i;
+            const int n = nb * 16 + 4 * (l >> 4);
+            const bool live = t < p.T && tb0 + j < p.Tb && nb < p.NB;
+            const float rinv = ep.ss_in ? s_rinv[tl] : 1.0f;
+            float y[4] = {v[h][q][0] * rinv, v[h][q][1] * rinv, v[h][q][2] * rinv, v[h][q][3] * rinv};
+            if (EPI == GemmEpilogue::F32) {
+                if (live) {
+                    float* o = ep.out + (size_t)t * ep.ldo + n;
+                    if (n + 3 < p.N && (ep.ldo & 3) == 0) {
+                        *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (n + r < p.N) o[r] = y[r];
+                    }
+                }
+            } else if (EPI == GemmEpilogue::SWIGLU_A16) {
+                if (i == 0 && live) {
+                    const f4_t u = red[0][1][j][l];
+                    float z[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], u[r] * rinv);
+                    const int hid = (nb >> 1) * 16 + 4 * (l >> 4);
+                    if constexpr (COH) store_a16_4_sc1(ep.a16_out, ep.Kb_out, t, hid, z);
+                    else store_a16_4(ep.a16_out, ep.Kb_out, t, hid, z);
+                }
+            } else if (EPI == GemmEpilogue::RESID_A16) {
+                if (live) {
+                    float* xr = ep.x + (size_t)t * p.N + n;
+                    const float4 xo = pf_x[h][q];
+                    const float4 g = pf_g[h][q];
+                    // residual add as the reference's accum(): x = x + branch (layers.c:163-168)
+                    const float xn[4] = {__fadd_rn(xo.x, y[0]), __fadd_rn(xo.y, y[1]), __fadd_rn(xo.z, y[2]), __fadd_rn(xo.w, y[3])};
+                    if constexpr (COH)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, make_float4(xn[0], xn[1], xn[2], xn[3])), rs_x,
+                                                               (t * p.N + n) * 4, 0, AUX_SC1);
+                    else
+                        *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+                    const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
+                    if constexpr (COH) store_a16_4_sc1(ep.a16_out, ep.Kb_out, t, n, z);
+                    else store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
+                    ssq[h][q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
+                }
+            } else {  // ROPE_KV
+                if (live) {
+                    if (n < ep.QD + ep.KD) {   // q or k: rotate the two pairs of this float4 (layers.c:118-141)
+                        const int d = (n < ep.QD ? n : n - ep.QD) % ep.hd;
+                        const float2* tab = ep.rope + (size_t)pf_pos * (ep.hd >> 1) + (d >> 1);
+                        const float2 c0 = tab[0], c1 = tab[1];
+                        const float a0 = y[0], b0 = y[1], a1 = y[2], b1 = y[3];
+                        y[0] = __fsub_rn(__fmul_rn(a0, c0.x), __fmul_rn(b0, c0.y));
+                        y[1] = __fadd_rn(__fmul_rn(a0, c0.y), __fmul_rn(b0, c0.x));
+                        y[2] = __fsub_rn(__fmul_rn(a1, c1.x), __fmul_rn(b1, c1.y));
+                        y[3] = __fadd_rn(__fmul_rn(a1, c1.y), __fmul_rn(b1, c1.x));
+                    }
+                    if (n < ep.QD) {
+                        if constexpr (COH) kv_put4_sc1<float>(ep.q_out + (size_t)t * ep.QD + n, y);
+                        else *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
+                    } else if (pf_row >= 0) {
+                        const long block = pf_row / ep.bs;
+                        const int key = pf_row % ep.bs;
+                        const bool is_k = n < ep.QD + ep.KD;
+                        const int c = is_k ? n - ep.QD : n - ep.QD - ep.KD;
+                        KVT* pool = reinterpret_cast<KVT*>(is_k ? ep.pool_k : ep.pool_v) + ep.layer_off;
+                        if (sizeof(KVT) == 4) {   // the reference's rows (memory.c:37-43)
+                            if constexpr (COH) kv_put4_sc1<KVT>(pool + (block * ep.bs + key) * ep.KD + c, y);
+                            else kv_put4<KVT>(pool + (block * ep.bs + key) * ep.KD + c, y);
+                        } else {                  // fp16 pages in matrix-core operand order
+                            const int kvh = c / ep.hd, d = c % ep.hd;
+                            KVT* page = pool + kv16_page(block, kvh, ep.KD / ep.hd, ep.hd);
+                            if constexpr (COH) {
+                                if (is_k) kv_put4_sc1<KVT>(page + kv16_k_off(key, d), y);
+                                else kv_put4_strided_sc1<KVT>(page + kv16_v_off(key, d), y);
+                            } else {
+                                if (is_k) kv_put4<KVT>(page + kv16_k_off(key, d), y);
+                                else kv_put4_strided<KVT>(page + kv16_v_off(key, d), y);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == GemmEpilogue::RESID_A16) {
+        // per-token sum of x^2 over each 32-feature group (= one round: two row blocks):
+        // over the 4 lane groups (l>>4), then over the round's two row blocks (i)
+        const int ss_cols = (p.N + 31) >> 5;
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < IPT; q++) {
+                float sq = ssq[h][q];
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                const int e = tid + q * NW * 64;
+                if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
+            }
+            __syncthreads();
+            if (tid < TB * 16) {
+                const int t = tb0 * 16 + tid;
+                const int col = ix.x * ROUNDS + h;
+                if (t < p.T && col < ss_cols) {
+                    const float sum = s_ss[0][tid] + s_ss[1][tid];
+                    if constexpr (COH)
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(ep.ss_out + (size_t)t * ss_cols + col),
+                                           __builtin_bit_cast(unsigned, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        ep.ss_out[(size_t)t * ss_cols + col] = sum;
+                }
+            }
+        }
+    }
+#ifdef NVLLM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores issued so far have left the CU
+#endif
+    NVLLM_TSTAMP(6, ssq[0][0]);
+    return true;
+}
+
+}  // namespace nvllm

@@ -42,6 +42,7 @@ struct ModelPriv {
     // forward pass runs the fp32 operators one by one.
     bool f32 = false;
     std::vector<void*> f32_bufs;
+    ChainLayer* chain_layers = nullptr;   // per-layer weight pointers in HBM, for the one-launch decode step (chain.hip)
 };
 
 // Does fp16 hold this fp32 value exactly?  (Zero, or a normal/subnormal fp16 value; no NaN.)
@@ -94,6 +95,7 @@ struct PassSlot {
     hipEvent_t ev = nullptr;
     long ticket = -1;
     int outputs = 0;
+    bool chained = false;   // the pass ran its layers as one launch: host[outputs] is that launch's status word
 };
 static PassSlot g_pass[PASS_RING];
 static long g_next_ticket = 0;
@@ -126,7 +128,7 @@ static void tp_gather_logits(float* full, const float* local, int rows, int slic
 
 // End of a forward pass: the copies that carry its results to the host are enqueued behind its
 // kernels and an event behind them; returns the pass's ticket.
-static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V) {
+static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V, bool chained = false) {
     const long ticket = g_next_ticket++;
     PassSlot& slot = g_pass[ticket % PASS_RING];
     if (slot.ticket >= 0) NVLLM_FATAL("forward pass %ld was never collected: at most %d passes may be in flight", slot.ticket, PASS_RING);
@@ -137,7 +139,9 @@ static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int 
     }
     if (!slot.ev) HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
     hipStream_t stream = rt().stream;
-    HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // (with the status word of a one-launch step, which sits right behind the indices)
+    HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)(B + (chained ? 1 : 0)) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    slot.chained = chained;
     if (rt().logits_mode == NVLLM_LOGITS_HOST)
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipEventRecord(slot.ev, stream));
@@ -157,6 +161,13 @@ static const int* collect_pass(long ticket, int* num_outputs) {
     PassSlot& slot = g_pass[ticket % PASS_RING];
     if (slot.ticket != ticket) NVLLM_FATAL("forward pass %ld is not in flight", ticket);
     HIP_CHECK(hipEventSynchronize(slot.ev));
+    if (slot.chained && slot.host[slot.outputs] != 1) {
+        const int st = slot.host[slot.outputs];
+        NVLLM_FATAL("the one-launch decode step did not complete (status %d: %s); set NVLLM_DECODE_CHAIN=0 to run the layers as separate kernels",
+                    st, (st & 4) ? "a workgroup waited for a hand-off longer than 0.2 s"
+                                 : (st & 2) ? "not all of its workgroups were resident at once -- is another process using this GPU?"
+                                            : "it never started");
+    }
     slot.ticket = -1;
     if (num_outputs) *num_outputs = slot.outputs;
     g_argmax_host = slot.host;
@@ -505,6 +516,17 @@ void load_model(Weights* w, Config* p, const char* checkpoint_path) {
     w->rms_final_weight = (float*)m->rms_final;
     w->lm_head = reg(m->head, Vh, D, str_D);
     w->_data_buffer = m;
+    {
+        std::vector<ChainLayer> tab((size_t)L);
+        for (int l = 0; l < L; l++) {
+            const LayerPriv& lp = m->layers[l];
+            tab[l] = ChainLayer{lp.qkv, lp.wo, lp.gateup, lp.down, lp.rms_ffn, l + 1 < L ? m->layers[l + 1].rms_att : m->rms_final};
+        }
+        void* d = nullptr;
+        if (device_malloc(&d, tab.size() * sizeof(ChainLayer)) != 0) NVLLM_FATAL("cannot allocate the layer table");
+        device_memcpy(d, tab.data(), tab.size() * sizeof(ChainLayer), HOST_TO_DEVICE);
+        m->chain_layers = (ChainLayer*)d;
+    }
 }
 
 void nvllm_free_model(Weights* w) {
@@ -512,6 +534,7 @@ void nvllm_free_model(Weights* w) {
     ModelPriv* m = (ModelPriv*)w->_data_buffer;
     for (const void* h : m->handles) unregister_weight(h);
     if (m->arena) device_free(m->arena);
+    if (m->chain_layers) device_free(m->chain_layers);
     for (void* q : m->f32_bufs) device_free(q);
     delete m;
     free(w->layers);
@@ -616,10 +639,42 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         return finish_pass(s, d_logits, d_argmax, B, V);
     }
 
+    // One launch for all layers (chain.hip) when the step fits it: a decode-sized batch on an fp16 page pool,
+    // the whole model on this GPU.  Its arrival counters and status word are cleared by the embedding kernel.
+    const bool try_chain = chain_enabled() && !partial && T <= 64 && pool.elem_bytes == 2 && m->chain_layers;
+    unsigned* chain_sync = nullptr;
+    unsigned* chain_status = (unsigned*)(d_argmax + B);
+    size_t sync_words = 0;
+    if (try_chain) {
+        sync_words = chain_sync_words(p->n_layers);
+        chain_sync = (unsigned*)ws_get(WS_CHAIN_SYNC, sync_words * sizeof(unsigned));
+    }
     // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
-    launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D, st.d_tok_src, d_argmax);
+    launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D, st.d_tok_src, d_argmax,
+                          chain_sync, (int)sync_words, try_chain ? chain_status : nullptr);
+    bool chained = false;
+    if (try_chain) {
+        ChainStep cs{};
+        cs.layers = m->chain_layers;
+        cs.n_layers = p->n_layers;
+        cs.T = T; cs.D = D; cs.F = F; cs.H = H; cs.KVH = KVH; cs.hd = hd;
+        cs.eps = eps;
+        cs.x = s->x; cs.a16_x = a16_x; cs.a16_att = a16_att; cs.a16_h = a16_h; cs.ss_a = ss_a; cs.ss_b = ss_b; cs.q = s->q;
+        cs.pos = st.d_pos; cs.kv_row = st.d_kv_row; cs.rope = rope;
+        cs.pool_k = pool.k; cs.pool_v = pool.v; cs.kv_elem_bytes = pool.elem_bytes; cs.block_size = pool.block_size;
+        cs.layer_stride = pool.layer_stride;
+        cs.tables = st.d_tables; cs.runs = st.d_runs; cs.n_runs = st.n_runs;
+        for (int i = 0; i < 4; i++) cs.runs_in_tb[i] = st.runs_in_tb[i];
+        cs.one_token_per_seq = st.one_token_per_seq;
+        cs.sync = chain_sync;
+        cs.status = chain_status;
+        const double wbytes = 2.0 * p->n_layers * ((double)D * QD + 2.0 * D * KD + (double)QD * D + 3.0 * D * F);
+        cs.bytes = wbytes + (double)st.kv_positions * 2.0 * KD * pool.elem_bytes * p->n_layers;
+        cs.flops = wbytes * T + 4.0 * (double)st.kv_positions * H * hd * p->n_layers;
+        chained = launch_decode_chain(cs);
+    }
 
-    for (int l = 0; l < p->n_layers; l++) {
+    for (int l = 0; l < p->n_layers && !chained; l++) {
         const LayerPriv& lp = m->layers[l];
         // q,k,v = rmsnorm(x) . [wq;wk;wv]^T, RoPE, K/V rows into the pool      (model.c:361-377)
         WeightEntry wqkv{lp.qkv, QD + 2 * KD, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
@@ -736,7 +791,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         }
     }
 
-    return finish_pass(s, d_logits, d_argmax, B, V);
+    return finish_pass(s, d_logits, d_argmax, B, V, chained);
 }
 
 void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,

@@ -117,6 +117,7 @@ enum WsSlot {
     WS_SAMPLE,      // a logits row handed to sample() that is not part of the last forward pass
     WS_TP_LOCAL,    // tensor parallelism: this rank's slice of the logits / its arg-max pairs
     WS_TP_GATHER,   // ... and what the ranks gathered
+    WS_CHAIN_SYNC,  // arrival counters of the one-launch decode step
     WS_COUNT
 };
 void* ws_get(WsSlot slot, size_t bytes);
@@ -145,6 +146,7 @@ enum ProfClass {
     PC_ELEMWISE,
     PC_ARGMAX,
     PC_PACK,
+    PC_CHAIN,      // all layers of a decode step in one launch (chain.hip)
     PC_COUNT
 };
 hipEvent_t prof_start_event();   // events of the enclosing ProfScope, or null when timing is off
@@ -220,8 +222,57 @@ struct GemmWorkspace {
 int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* a16, int T,
                 const GemmEpilogue& epi, int force_ksplit, int prof_cls, const GemmWorkspace* wsp = nullptr);
 int gemm_pick_ksplit(int N, int K, int T);
+struct GemmPlan {
+    int nbw, TB, nw;         // 16-row blocks per tile, 16-token blocks per group, waves per workgroup
+    int ks, kb_per_split;    // K slices and k-tiles per slice
+    int tiles_n, tiles_t;    // grid: feature tiles (padding included) x K slices x token groups
+};
+GemmPlan gemm_plan(int N, int K, int T, int epi_kind, int force_ksplit, long max_counters, size_t slab_cap);
 int gemm_feature_tiles(int N);   // 32-feature groups of a projection output = columns of ss_out
 void gemm_release();
+
+unsigned* gemm_tile_counters();   // the split-K arrival counters (allocated on first use, zero between launches)
+
+// ---- chain.hip: the layers of one decode step as one launch
+struct ChainLayer {           // per layer, in HBM (built by load_model)
+    const __half* qkv;
+    const __half* wo;
+    const __half* gateup;
+    const __half* down;
+    const float* gain_ffn;    // the gain that follows the output projection
+    const float* gain_next;   // the gain that follows the down projection (next layer's, or the final norm's)
+};
+struct ChainStep {
+    const ChainLayer* layers;
+    int n_layers;
+    int T, D, F, H, KVH, hd;
+    float eps;
+    float* x;
+    __half* a16_x;
+    __half* a16_att;
+    __half* a16_h;
+    float* ss_a;
+    float* ss_b;
+    float* q;
+    const int* pos;
+    const int* kv_row;
+    const float2* rope;
+    void* pool_k;
+    void* pool_v;
+    int kv_elem_bytes, block_size;
+    long layer_stride;
+    const int* tables;
+    const int* runs;
+    int n_runs;
+    int runs_in_tb[4];        // attention work items' runs that touch each 16-token block
+    bool one_token_per_seq;   // every sequence of the step contributes exactly one token (pure decode)
+    unsigned* sync;           // chain_sync_words() words, zero when the launch starts
+    unsigned* status;         // one word, zero when the launch starts (see chain.hip)
+    double bytes, flops;      // algorithmic bytes / flops of the launch, for the kernel timing classes
+};
+int chain_enabled();
+size_t chain_sync_words(int n_layers);
+bool launch_decode_chain(const ChainStep& s);
 
 void launch_pack_a16(__half* a16, const float* in, int T, int K);
 void launch_matmul_f32w(float* out, const float* in, const float* w, int T, int K, int N);
@@ -283,8 +334,10 @@ int attn_tokens_per_item(int H, int KVH);
 
 // x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 32j..32j+31
 // tok_src / prev (optional): where tok_src[t] >= 0 the token id is prev[tok_src[t]] instead of tokens[t]
+// zero / n_zero (optional): words the kernel also clears (state of the launch that follows it)
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
-                           const float* gain, int T, int D, const int* tok_src = nullptr, const int* prev = nullptr);
+                           const float* gain, int T, int D, const int* tok_src = nullptr, const int* prev = nullptr,
+                           unsigned* zero = nullptr, int n_zero = 0, unsigned* zero_word = nullptr);
 // x[t,:] += y[t,:]; a16 = x * gain in hi/lo tiles; ss as above (the tail of a residual projection
 // whose sums were completed outside the projection kernel)
 void launch_resid_prescale(float* x, const float* y, __half* a16, float* ss, const float* gain, int T, int D);

@@ -90,7 +90,18 @@ StepArrays stage_step(const int* tokens, const int* pos_arr, const int* seq_ids,
             runs.push_back(pos_of(t + n - 1));
             runs.push_back(tbl_off[seq_of(t)]);
             s.kv_positions += pos_of(t + n - 1) + 1;
+            for (int tb = t >> 4; tb <= (t + n - 1) >> 4; tb++)
+                if (tb < 4) s.runs_in_tb[tb]++;
             t += n;
+        }
+    }
+    {   // does any sequence occur twice?
+        std::vector<char> seen(n_seqs, 0);
+        s.one_token_per_seq = true;
+        for (int t = 0; t < T && s.one_token_per_seq; t++) {
+            const int sid = seq_ids ? seq_ids[t] : 0;
+            if (seen[sid]) s.one_token_per_seq = false;
+            seen[sid] = 1;
         }
     }
     s.n_runs = (int)runs.size() / 4;

@@ -179,7 +179,8 @@ static void prof_drain() {
 
 static const char* kProfNames[PC_COUNT] = {
     "embed",      "rmsnorm",  "gemm_qkv", "gemm_wo",      "gemm_gateup", "gemm_down", "gemm_head",
-    "gemm_other", "rope_kv",  "attn",     "attn_combine", "elementwise", "argmax",    "pack"};
+    "gemm_other", "rope_kv",  "attn",     "attn_combine", "elementwise", "argmax",    "pack",
+    "decode_chain"};
 
 // --------------------------------------------------------------------- init
 void ensure_init() {

@@ -21,6 +21,8 @@ struct StepArrays {
     int* d_runs;      // [n_runs][4] (first token, count, last position, table offset): attention work items
     int n_runs;
     long kv_positions;
+    int runs_in_tb[4];       // runs that touch each of the first four 16-token blocks
+    bool one_token_per_seq;  // no sequence contributes more than one token (a pure decode step)
 };
 
 // Copies the arrays into the pinned ring, lays the block tables of the sequences
