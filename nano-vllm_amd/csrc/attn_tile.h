@@ -72,13 +72,17 @@ struct Attn16Wave {
     // only) says which pages may hold rows written during this launch: 0 = any page, 1 = only the
     // page of the item's last position (a batch in which every sequence has exactly one token).
     __device__ __forceinline__ void setup(const AttnKArgs& args, unsigned widx, int wave_in_item, int lane_, int fresh_rule) {
+        const unsigned rest = widx / (unsigned)args.NG;
+        setup(args, widx, wave_in_item, lane_, fresh_rule, args.runs[rest / (unsigned)args.nsplit]);
+    }
+    // the same for a caller that already holds the item's run descriptor
+    __device__ __forceinline__ void setup(const AttnKArgs& args, unsigned widx, int wave_in_item, int lane_, int fresh_rule, const int4 run) {
         a = args;
         lane = lane_;
         const unsigned NG = (unsigned)args.NG;
         const int hg = (int)(widx % NG);
         const unsigned rest = widx / NG;
         split = (int)(rest % (unsigned)args.nsplit);
-        const int4 run = args.runs[rest / (unsigned)args.nsplit];
         t0 = run.x, ntok = run.y, plast = run.z;
         h0 = hg * args.GT;
         kvh = (int)((unsigned)h0 / (unsigned)args.group);
@@ -93,8 +97,13 @@ struct Attn16Wave {
         pg_end = min(npages, split * per + per);
         fresh_page = !COH ? 0x7fffffff : (fresh_rule == 0 ? 0 : (plast >> 4));
         table = args.tables + run.w;
-        pk = reinterpret_cast<const __half*>(args.pool_k) + args.layer_off;
-        pv = reinterpret_cast<const __half*>(args.pool_v) + args.layer_off;
+        begin(args.layer_off);
+    }
+    // a new pass over the item's pages, in the pool slice that starts `layer_off` elements in (a caller
+    // that works through the layers calls setup() once and begin() per layer)
+    __device__ __forceinline__ void begin(long layer_off) {
+        pk = reinterpret_cast<const __half*>(a.pool_k) + layer_off;
+        pv = reinterpret_cast<const __half*>(a.pool_v) + layer_off;
         m = -INFINITY, lsum = 0.f;
 #pragma unroll
         for (int n = 0; n < NC; n++) oacc[n] = af4_t{0.f, 0.f, 0.f, 0.f};
@@ -286,9 +295,11 @@ struct Attn16Wave {
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.out_a16 + (tl + pl) * TILE_HALVES + off);
-            if constexpr (COH) {
-                __hip_atomic_store(dst, q0[pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, q1[pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (COH) {   // one 16-byte write-through store (aux 16 = sc1) through a descriptor of the whole buffer
+                typedef unsigned int au4_t __attribute__((ext_vector_type(4)));
+                const au4_t v = {(unsigned)q0[pl], (unsigned)(q0[pl] >> 32), (unsigned)q1[pl], (unsigned)(q1[pl] >> 32)};
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.out_a16, 0, 0x7ffffff0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((tl + pl) * TILE_HALVES + off) * 2), 0, 16);
             } else {
                 *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2(q0[pl], q1[pl]);
             }

@@ -33,6 +33,9 @@ constexpr int CH_PHASES = 5;
 enum ChainPhase { PH_QKV = 0, PH_ATT = 1, PH_WO = 2, PH_GU = 3, PH_DN = 4 };
 constexpr int CH_TBMAX = 4;           // 16-token blocks per step (64 tokens)
 constexpr int CH_LINE = 32;           // words between two counters (one 128-byte line each)
+constexpr int CH_REP = 8;             // replicas of every arrival counter: a producer adds to all of them with one wave
+                                      // instruction, a consumer polls the one of its workgroup number modulo 8, so that
+                                      // the chip's pollers are spread over eight lines (memory channels) per counter
 constexpr unsigned CH_GO = 1, CH_ABORT = 2;
 constexpr unsigned long long CH_WAIT_TICKS = 20000000ull;    // 0.2 s of the 100 MHz constant clock
 constexpr unsigned long long CH_CENSUS_TICKS = 5000000ull;   // 50 ms
@@ -77,7 +80,7 @@ struct ChainArgs {
     unsigned long long* stamps;             // diagnostic builds: [layer * 5 + phase][workgroup][8]
 };
 
-size_t chain_sync_words(int n_layers) { return 64 + (size_t)n_layers * CH_PHASES * CH_TBMAX * CH_LINE; }
+size_t chain_sync_words(int n_layers) { return 64 + (size_t)n_layers * CH_PHASES * CH_TBMAX * CH_REP * CH_LINE; }
 
 // The launch record is read where it is needed, straight from the kernel-argument segment (scalar
 // loads).  Held as an ordinary by-value parameter its hundred-odd words would sit in scalar
@@ -97,7 +100,7 @@ __device__ __forceinline__ T karg(const T __attribute__((address_space(4))) * p)
 }
 
 __device__ __forceinline__ unsigned* chain_counter(KArgs k, int layer, int phase) {
-    return k->sync + 64 + (size_t)(layer * CH_PHASES + phase) * CH_TBMAX * CH_LINE;
+    return k->sync + 64 + (size_t)(layer * CH_PHASES + phase) * CH_TBMAX * CH_REP * CH_LINE;
 }
 __device__ __forceinline__ unsigned long long chain_clock() { return __builtin_amdgcn_s_memrealtime(); }
 
@@ -151,7 +154,7 @@ __device__ __forceinline__ void chain_wait(KArgs k, const unsigned* counters, in
         const int lane = threadIdx.x;
         const unsigned want = lane == 0 ? k->expect[phase][0] : lane == 1 ? k->expect[phase][1] : lane == 2 ? k->expect[phase][2] : k->expect[phase][3];
         const bool mine = lane < CH_TBMAX && ((mask >> lane) & 1u);
-        const unsigned* word = counters + (lane < CH_TBMAX ? lane : 0) * CH_LINE;
+        const unsigned* word = counters + ((lane < CH_TBMAX ? lane : 0) * CH_REP + (blockIdx.x % CH_REP)) * CH_LINE;
         const unsigned long long t0 = chain_clock();
         for (;;) {
             const unsigned v = mine ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : want;
@@ -173,8 +176,8 @@ __device__ __forceinline__ void chain_wait(KArgs k, const unsigned* counters, in
 __device__ __forceinline__ void chain_publish(unsigned* counters, bool wrote, int tb_lo, int tb_hi) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (wrote && (int)threadIdx.x < tb_hi - tb_lo)
-        __hip_atomic_fetch_add(counters + (tb_lo + threadIdx.x) * CH_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wrote && (int)threadIdx.x < (tb_hi - tb_lo) * CH_REP)   // lane = (token block, replica)
+        __hip_atomic_fetch_add(counters + (tb_lo * CH_REP + threadIdx.x) * CH_LINE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // An opaque copy: the compiler cannot tell that it equals its argument, so nothing computed from it
@@ -222,10 +225,18 @@ __device__ __forceinline__ GemmArgs chain_gemm_args(KArgs k, const ChainProj& g,
 #endif
     return p;
 }
+// Diagnostic builds: eight clock readings per (layer, phase, workgroup); a projection tile writes 0..6
+// (gemm_tile.h), the chain adds 7 = the tile's arrival has been published.
 #ifdef NVLLM_STAMPS
 #define CHAIN_STAMPS(p, k, l, ph) do { if ((k)->stamps) (p).stamps = (k)->stamps + (size_t)((l) * CH_PHASES + (ph)) * gridDim.x * 8; } while (0)
+#define CHAIN_STAMP_END(k, l, ph)                                                                                           \
+    do {                                                                                                                    \
+        if ((k)->stamps && threadIdx.x == 0)                                                                                \
+            (k)->stamps[((size_t)((l) * CH_PHASES + (ph)) * gridDim.x + blockIdx.x) * 8 + 7] = chain_clock();                \
+    } while (0)
 #else
 #define CHAIN_STAMPS(p, k, l, ph) do {} while (0)
+#define CHAIN_STAMP_END(k, l, ph) do {} while (0)
 #endif
 
 // S: the tile shapes of the four projections (row blocks per tile, token blocks per group, weight
@@ -247,6 +258,23 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
     const bool on_a = b < n_items;            // this workgroup's attention item
     const bool att_wave = on_a && wave < 4;   // (four waves share an item)
 
+    // The attention item of this workgroup is the same in every layer: its run descriptor is looked up once.
+    int4 run = make_int4(0, 1, 0, 0);
+    int tb_a0 = 0, tb_a1 = 0;
+    unsigned ma = 0;
+    {
+        KArgs k = chain_kargs();
+        if (on_a) {
+            run = k->att.runs[(unsigned)b / (unsigned)k->att.NG];
+            run = make_int4(__builtin_amdgcn_readfirstlane(run.x), __builtin_amdgcn_readfirstlane(run.y),
+                            __builtin_amdgcn_readfirstlane(run.z), __builtin_amdgcn_readfirstlane(run.w));
+            tb_a0 = run.x >> 4;
+            tb_a1 = ((run.x + run.y - 1) >> 4) + 1;
+            // one token per sequence: the item needs its own token's q and K/V row only; otherwise keys of
+            // the step's other tokens too (a prompt chunk): everything the q/k/v phase writes
+            ma = k->fresh_rule == 1 ? ((1u << tb_a1) - 1u) & ~((1u << tb_a0) - 1u) : (1u << k->Tb) - 1u;
+        }
+    }
     // Weight rings: each is declared where its prefetch is issued, so that no value of an earlier
     // layer stays live in registers; only the q/k/v ring crosses from one layer to the next.
     h8_t wq[S::Q_RW][S::Q_NBW];
@@ -259,26 +287,22 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
     }
     for (int l = 0; l < n_layers; l++) {
         // ---------------------------------------------------------------- q, k, v (+ RoPE, K/V rows into the pool)
-        AttnKArgs ak;
-        Attn16Wave<S::HD, 2, 4, true> aw;
         h8_t ww[S::W_RW][S::W_NBW];
+        Attn16Wave<S::HD, 2, 4, true> aw;
         bool att_started = false;
-        auto attention_head_start = [&] {   // block ids and the first pages, if none of them changes in this launch
+        {
             const int tid = chain_opaque_v((int)threadIdx.x);
             KArgs k = chain_kargs();
-            ak = karg(&k->att);
+            // this layer's attention: the first pages are requested now if none of them can change in this launch
+            AttnKArgs ak = karg(&k->att);
             ak.layer_off = (long)l * k->layer_stride;
-            aw.setup(ak, (unsigned)(on_a ? b : 0), wave & 3, tid & 63, k->fresh_rule);   // (every field defined on every path)
+            aw.setup(ak, (unsigned)(on_a ? b : 0), wave & 3, tid & 63, k->fresh_rule, run);
             if (att_wave && aw.start_is_stable()) {
                 aw.start();
                 att_started = true;
             } else {
                 aw.clear_ring();
             }
-        };
-        {
-            const int tid = chain_opaque_v((int)threadIdx.x);
-            KArgs k = chain_kargs();
             const ChainProj g = karg(&k->qkv);
             const ChainTile t = chain_tile(g, b, S::Q_TB, k->Tb);
             GemmArgs p = chain_gemm_args(k, g, k->layers[l].qkv, k->a16_x);
@@ -293,25 +317,20 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             bool wrote = false;
             if (t.on)
                 wrote = gemm_tile<S::Q_NBW, S::Q_TB, CH_NW, S::Q_RW, 2, GemmEpilogue::ROPE_KV, typename S::KVT, true, true>(
-                    p, t.ix, lds_dyn, wq, attention_head_start, tid);
-            else
-                attention_head_start();
+                    p, t.ix, lds_dyn, wq, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_QKV), wrote, t.tb_lo, t.tb_hi);
+            CHAIN_STAMP_END(k, l, PH_QKV);
         }
         // ---------------------------------------------------------------- attention over the block table
         {
             const int tid = chain_opaque_v((int)threadIdx.x);
             KArgs k = chain_kargs();
-            unsigned ma = 0;
-            int tb_a0 = 0, tb_a1 = 0;
-            if (on_a) {
-                const int4 run = k->att.runs[(unsigned)b / (unsigned)k->att.NG];
-                tb_a0 = run.x >> 4;
-                tb_a1 = ((run.x + run.y - 1) >> 4) + 1;
-                // one token per sequence: the item needs its own token's q and K/V row only; otherwise keys of
-                // the step's other tokens too (a prompt chunk): everything the q/k/v phase writes
-                ma = k->fresh_rule == 1 ? ((1u << tb_a1) - 1u) & ~((1u << tb_a0) - 1u) : (1u << k->Tb) - 1u;
-            }
+            const ChainProj gw = karg(&k->wo);
+            const ChainTile tw = chain_tile(gw, b, S::W_TB, k->Tb);
+            const GemmArgs pw = chain_gemm_args(k, gw, k->layers[l].wo, k->a16_att);
+            // the output projection's weights: the waves that take no part in attention request theirs now,
+            // the others after their page loop
+            if (wave >= 4) gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, tw.ix, ww, tid, tw.on);
             chain_wait(k, chain_counter(k, l, PH_QKV), PH_QKV, ma, s_word);
 #ifdef NVLLM_STAMPS
             unsigned long long* const st = k->stamps ? k->stamps + ((size_t)(l * CH_PHASES + PH_ATT) * gridDim.x + b) * 8 : nullptr;
@@ -320,23 +339,24 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             if (att_wave) {
                 aw.load_q();
                 if (!att_started) aw.start();
+#ifdef NVLLM_STAMPS
+                if (st && threadIdx.x == 0) st[1] = chain_clock();
+#endif
                 aw.loop();
             }
 #ifdef NVLLM_STAMPS
             if (st && threadIdx.x == 0) st[3] = chain_clock();
 #endif
-            {   // the output projection's weights travel while the item is merged and stored
-                const ChainProj g = karg(&k->wo);
-                const ChainTile t = chain_tile(g, b, S::W_TB, k->Tb);
-                const GemmArgs pw = chain_gemm_args(k, g, k->layers[l].wo, k->a16_att);
-                gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, t.ix, ww, tid, t.on);
-            }
+            if (wave < 4) gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, tw.ix, ww, tid, tw.on);
             if (att_wave) aw.deposit(lds_dyn, wave);
             __syncthreads();
             if (att_wave) aw.merge(lds_dyn, wave);
-            chain_publish(chain_counter(k, l, PH_ATT), on_a, tb_a0, tb_a1);
 #ifdef NVLLM_STAMPS
             if (st && threadIdx.x == 0) st[6] = chain_clock();
+#endif
+            chain_publish(chain_counter(k, l, PH_ATT), on_a, tb_a0, tb_a1);
+#ifdef NVLLM_STAMPS
+            if (st && threadIdx.x == 0) st[7] = chain_clock();
 #endif
         }
         h8_t wg[S::G_RW][S::G_NBW], wd[S::D_RW][S::D_NBW];
@@ -352,20 +372,18 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             p.e.x = k->x; p.e.gain_next = L.gain_ffn; p.e.a16_out = k->a16_x; p.e.ss_out = k->ss_b;
             p.e.Kb_out = (k->D + 31) >> 5;
             CHAIN_STAMPS(p, k, l, PH_WO);
+            const ChainProj gn = karg(&k->gu);
+            const ChainTile tn = chain_tile(gn, b, S::G_TB, k->Tb);
+            const GemmArgs pn = chain_gemm_args(k, gn, L.gateup, k->a16_x);
             chain_wait(k, chain_counter(k, l, PH_ATT), PH_ATT, t.mask, s_word);
             bool wrote = false;
             h8_t wg_new[S::G_RW][S::G_NBW];
-            auto next = [&] {
-                const ChainProj gn = karg(&k->gu);
-                const ChainTile tn = chain_tile(gn, b, S::G_TB, k->Tb);
-                const GemmArgs pn = chain_gemm_args(k, gn, L.gateup, k->a16_x);
-                gemm_tile_prefetch<S::G_NBW, CH_NW, S::G_RW>(pn, tn.ix, wg_new, tid, tn.on);
-            };
             if (t.on)
-                wrote = gemm_tile<S::W_NBW, S::W_TB, CH_NW, S::W_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, ww, next, tid);
-            else
-                next();
+                wrote = gemm_tile<S::W_NBW, S::W_TB, CH_NW, S::W_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, ww, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_WO), wrote, t.tb_lo, t.tb_hi);
+            CHAIN_STAMP_END(k, l, PH_WO);
+            // the next tile's weights travel while the other workgroups finish theirs
+            gemm_tile_prefetch<S::G_NBW, CH_NW, S::G_RW>(pn, tn.ix, wg_new, tid, tn.on);
 #pragma unroll
             for (int s = 0; s < S::G_RW; s++)
 #pragma unroll
@@ -384,20 +402,17 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             p.e.a16_out = k->a16_h;
             p.e.Kb_out = (k->F + 31) >> 5;
             CHAIN_STAMPS(p, k, l, PH_GU);
+            const ChainProj gn = karg(&k->dn);
+            const ChainTile tn = chain_tile(gn, b, S::D_TB, k->Tb);
+            const GemmArgs pn = chain_gemm_args(k, gn, L.down, k->a16_h);
             chain_wait(k, chain_counter(k, l, PH_WO), PH_WO, t.mask, s_word);
             bool wrote = false;
             h8_t wd_new[S::D_RW][S::D_NBW];
-            auto next = [&] {
-                const ChainProj gn = karg(&k->dn);
-                const ChainTile tn = chain_tile(gn, b, S::D_TB, k->Tb);
-                const GemmArgs pn = chain_gemm_args(k, gn, L.down, k->a16_h);
-                gemm_tile_prefetch<S::D_NBW, CH_NW, S::D_RW>(pn, tn.ix, wd_new, tid, tn.on);
-            };
             if (t.on)
-                wrote = gemm_tile<S::G_NBW, S::G_TB, CH_NW, S::G_RW, 2, GemmEpilogue::SWIGLU_A16, float, true, true>(p, t.ix, lds_dyn, wg, next, tid);
-            else
-                next();
+                wrote = gemm_tile<S::G_NBW, S::G_TB, CH_NW, S::G_RW, 2, GemmEpilogue::SWIGLU_A16, float, true, true>(p, t.ix, lds_dyn, wg, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_GU), wrote, t.tb_lo, t.tb_hi);
+            CHAIN_STAMP_END(k, l, PH_GU);
+            gemm_tile_prefetch<S::D_NBW, CH_NW, S::D_RW>(pn, tn.ix, wd_new, tid, tn.on);
 #pragma unroll
             for (int s = 0; s < S::D_RW; s++)
 #pragma unroll
@@ -416,20 +431,17 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             p.e.Kb_out = (k->D + 31) >> 5;
             CHAIN_STAMPS(p, k, l, PH_DN);
             const bool more = l + 1 < n_layers;
+            const ChainProj gn = karg(&k->qkv);
+            const ChainTile tn = chain_tile(gn, b, S::Q_TB, k->Tb);
+            const GemmArgs pn = chain_gemm_args(k, gn, k->layers[more ? l + 1 : l].qkv, k->a16_x);
             chain_wait(k, chain_counter(k, l, PH_GU), PH_GU, t.mask, s_word);
             bool wrote = false;
             h8_t wq_new[S::Q_RW][S::Q_NBW];
-            auto next = [&] {
-                const ChainProj gn = karg(&k->qkv);
-                const ChainTile tn = chain_tile(gn, b, S::Q_TB, k->Tb);
-                const GemmArgs pn = chain_gemm_args(k, gn, k->layers[more ? l + 1 : l].qkv, k->a16_x);
-                gemm_tile_prefetch<S::Q_NBW, CH_NW, S::Q_RW>(pn, tn.ix, wq_new, tid, more && tn.on);
-            };
             if (t.on)
-                wrote = gemm_tile<S::D_NBW, S::D_TB, CH_NW, S::D_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, wd, next, tid);
-            else
-                next();
+                wrote = gemm_tile<S::D_NBW, S::D_TB, CH_NW, S::D_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, wd, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_DN), wrote, t.tb_lo, t.tb_hi);
+            CHAIN_STAMP_END(k, l, PH_DN);
+            gemm_tile_prefetch<S::Q_NBW, CH_NW, S::Q_RW>(pn, tn.ix, wq_new, tid, more && tn.on);
 #pragma unroll
             for (int s = 0; s < S::Q_RW; s++)
 #pragma unroll

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void k_embed_prescale(float* __restrict__ x, _
                                                         const int* __restrict__ tok_src, const int* __restrict__ prev,
                                                         unsigned* __restrict__ zero, int n_zero, unsigned* __restrict__ zero_word) {
     const int t = blockIdx.x;
-    // words the next launch expects to find zero (arrival counters of the decode chain)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = 0u;
+    // words the next launch expects to find zero (arrival counters of the decode chain: the first word of each 128-byte line)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[(size_t)i * 32] = 0u;
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
     // a token the host has not seen yet: the arg-max the previous pass left in HBM
     const int tok = (tok_src && tok_src[t] >= 0) ? prev[tok_src[t]] : tokens[t];

@@ -43,16 +43,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gemm_rsrc(const void* base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// 4 consecutive k of token t into hi/lo tiles with write-through stores (n % 4 == 0)
-__device__ __forceinline__ void store_a16_4_sc1(__half* a16, int Kb_out, int t, int n, const float* y) {
+// 4 consecutive k of token t into hi/lo tiles with write-through stores (n % 4 == 0), 16 bytes per
+// lane: the lane that holds k..k+3 and the lane 16 further on, which holds k+4..k+7 of the same
+// token, are both active here; the first gets both hi halves and stores the hi plane's 16-byte
+// chunk, the second both lo halves and stores the lo plane's (narrow write-through stores each cost
+// a transaction of their own on the way to memory).  `rs` covers the whole a16 buffer.
+__device__ __forceinline__ void store_a16_4_sc1(__amdgpu_buffer_rsrc_t rs, int Kb_out, int t, int n, const float* y, int lane) {
     alignas(8) __half hi[4], lo[4];
     split16_4(y, hi, lo);
-    const size_t tile = ((size_t)(t >> 4) * Kb_out + (n >> 5)) * 2;
-    const size_t off = (size_t)((t & 15) + 16 * ((n >> 3) & 3)) * 8 + (n & 7);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(a16 + tile * TILE_HALVES + off),
-                       *reinterpret_cast<unsigned long long*>(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(a16 + (tile + 1) * TILE_HALVES + off),
-                       *reinterpret_cast<unsigned long long*>(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u2_t H = *reinterpret_cast<const u2_t*>(hi), L = *reinterpret_cast<const u2_t*>(lo);
+    const bool first = (lane & 16) == 0;          // k % 8 == 0
+    const u2_t send = first ? L : H;
+    u2_t recv;
+    recv[0] = (unsigned)__shfl_xor((int)send[0], 16, 64);
+    recv[1] = (unsigned)__shfl_xor((int)send[1], 16, 64);
+    const u4_t out = first ? u4_t{H[0], H[1], recv[0], recv[1]} : u4_t{recv[0], recv[1], L[0], L[1]};
+    const int k8 = n & ~7;
+    const int tile = ((t >> 4) * Kb_out + (k8 >> 5)) * 2 + (first ? 0 : 1);
+    const int off = ((t & 15) + 16 * ((k8 >> 3) & 3)) * 8;
+    __builtin_amdgcn_raw_buffer_store_b128(out, rs, (tile * TILE_HALVES + off) * 2, 0, AUX_SC1);
 }
 
 template <typename KVT>
@@ -90,8 +99,11 @@ __device__ __forceinline__ void kv_put4_strided_sc1<__half>(__half* dst, const f
 // Must be followed by gemm_tile<..., PRE = true> with the same arguments.
 // `tid` = threadIdx.x (a caller that runs many tiles in a loop passes it through an opaque copy, so that
 // the compiler does not hoist every tile's per-lane index arithmetic out of that loop and keep it in registers).
+// part / nparts: only the ring entries s with s * nparts / RW == part (a caller that spreads the
+// requests over several places calls once per part); part < 0: all of them.
 template <int NBW, int NW, int RW>
-__device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const TileIdx ix, h8_t (&w)[RW][NBW], const int tid, const bool on = true) {
+__device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const TileIdx ix, h8_t (&w)[RW][NBW], const int tid, const bool on = true,
+                                                   const int part = -1, const int nparts = 1) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb0 = ix.x * NBW;
@@ -104,6 +116,7 @@ __device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const Tile
     const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < RW; s++) {
+        if (part >= 0 && (s * nparts) / RW != part) continue;
         if (s < nsteps) {
             const int kb = first + NW * s;
 #pragma unroll
@@ -118,11 +131,12 @@ __device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const Tile
 }
 
 // One tile.  Returns true when this workgroup wrote the tile's results (false: grid padding, or a
-// K slice that was not the last to arrive).  `after_loop()` runs once the K loop has consumed its
-// last operands and before the reduction and the epilogue: the place to start loads for later work.
+// K slice that was not the last to arrive).  `slot_free(r)` is called exactly once for every r in
+// [0, RW), as soon as the wave will not load ring entry r again for this tile -- inside the K loop,
+// spread over its last RW steps: the place to start loads for later work, a few at a time.
 template <int NBW, int TB, int NW, int RW, int RA, int EPI, typename KVT, bool COH, bool PRE, typename Hook>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, unsigned char* lds_dyn, h8_t (&w)[RW][NBW],
-                                          Hook&& after_loop, const int tid) {
+                                          Hook&& slot_free, const int tid) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
     static_assert(RW % RA == 0, "the activation ring must divide the weight ring");
     constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
@@ -141,7 +155,8 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb0 = ix.x * NBW;
     if (nb0 >= p.NB) {   // grid padded for XCD alignment
-        after_loop();
+#pragma unroll
+        for (int r = 0; r < RW; r++) slot_free(r);
         return false;
     }
 #ifdef NVLLM_STAMPS
@@ -240,6 +255,8 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                     const int kbw = kb_of(s + RW);
 #pragma unroll
                     for (int i = 0; i < NBW; i++) w[r][i] = NVLLM_WLOAD(wp[i] + (size_t)kbw * 64);
+                } else {
+                    slot_free(r);
                 }
                 if (s + RA < nsteps) {
                     const int kba = kb_of(s + RA);
@@ -249,8 +266,10 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < RW; r++)
+        if (r >= nsteps) slot_free(r);   // entries a short K slice never used
     NVLLM_TSTAMP(3, acc[NBW - 1][TB - 1][0]);
-    after_loop();
     // ---- 0. epilogue operands that do not depend on the sums: issue their loads now,
     // so that they travel while the K split is being closed (every workgroup does it;
     // only the one that ends up running the epilogue uses them).  Indices are clamped,
@@ -259,6 +278,8 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     float4 pf_x[ROUNDS][IPT], pf_g[ROUNDS][IPT];
     int pf_pos = 0, pf_row = -1;
     __amdgpu_buffer_rsrc_t rs_x = gemm_rsrc(ep.x, (unsigned)p.T * (unsigned)p.N * 4u);
+    __amdgpu_buffer_rsrc_t rs_o = gemm_rsrc(ep.a16_out, (unsigned)p.Tb * (unsigned)ep.Kb_out * 2048u);
+    __amdgpu_buffer_rsrc_t rs_q = gemm_rsrc(ep.q_out, (unsigned)p.T * (unsigned)ep.QD * 4u);
     if (EPI == GemmEpilogue::RESID_A16) {
 #pragma unroll
         for (int h = 0; h < ROUNDS; h++)
@@ -420,7 +441,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
 #pragma unroll
                     for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], u[r] * rinv);
                     const int hid = (nb >> 1) * 16 + 4 * (l >> 4);
-                    if constexpr (COH) store_a16_4_sc1(ep.a16_out, ep.Kb_out, t, hid, z);
+                    if constexpr (COH) store_a16_4_sc1(rs_o, ep.Kb_out, t, hid, z, l);
                     else store_a16_4(ep.a16_out, ep.Kb_out, t, hid, z);
                 }
             } else if (EPI == GemmEpilogue::RESID_A16) {
@@ -436,7 +457,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                     else
                         *reinterpret_cast<float4*>(xr) = make_float4(xn[0], xn[1], xn[2], xn[3]);
                     const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
-                    if constexpr (COH) store_a16_4_sc1(ep.a16_out, ep.Kb_out, t, n, z);
+                    if constexpr (COH) store_a16_4_sc1(rs_o, ep.Kb_out, t, n, z, l);
                     else store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
                     ssq[h][q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
                 }
@@ -453,7 +474,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                         y[3] = __fadd_rn(__fmul_rn(a1, c1.y), __fmul_rn(b1, c1.x));
                     }
                     if (n < ep.QD) {
-                        if constexpr (COH) kv_put4_sc1<float>(ep.q_out + (size_t)t * ep.QD + n, y);
+                        if constexpr (COH)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, make_float4(y[0], y[1], y[2], y[3])), rs_q,
+                                                                   (t * ep.QD + n) * 4, 0, AUX_SC1);
                         else *reinterpret_cast<float4*>(ep.q_out + (size_t)t * ep.QD + n) = make_float4(y[0], y[1], y[2], y[3]);
                     } else if (pf_row >= 0) {
                         const long block = pf_row / ep.bs;

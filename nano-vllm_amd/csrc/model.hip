@@ -651,7 +651,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     }
     // x = embedding rows; a16_x = x * rms_att[0]; ss_a = per-tile sums of x^2   (model.c:352-355,361)
     launch_embed_prescale(s->x, a16_x, ss_a, m->embed, st.d_tokens, m->layers[0].rms_att, T, D, st.d_tok_src, d_argmax,
-                          chain_sync, (int)sync_words, try_chain ? chain_status : nullptr);
+                          chain_sync, (int)(sync_words / 32), try_chain ? chain_status : nullptr);
     bool chained = false;
     if (try_chain) {
         ChainStep cs{};

@@ -334,7 +334,8 @@ int attn_tokens_per_item(int H, int KVH);
 
 // x[t,:] = table[tokens[t],:]; a16 = x * gain in hi/lo tiles; ss[t, j] = sum of x^2 over features 32j..32j+31
 // tok_src / prev (optional): where tok_src[t] >= 0 the token id is prev[tok_src[t]] instead of tokens[t]
-// zero / n_zero (optional): words the kernel also clears (state of the launch that follows it)
+// zero / n_zero (optional): the kernel also clears word 0 of n_zero consecutive 128-byte lines at `zero`, and
+// *zero_word (state of the launch that follows it)
 void launch_embed_prescale(float* x, __half* a16, float* ss, const __half* table, const int* tokens,
                            const float* gain, int T, int D, const int* tok_src = nullptr, const int* prev = nullptr,
                            unsigned* zero = nullptr, int n_zero = 0, unsigned* zero_word = nullptr);
