@@ -63,14 +63,16 @@ int  nvllm_get_kv_elem_bytes(void);
 
 /* -------------------------------------------------- one launch per decode step */
 /* No counterpart in the reference, whose layer loop (src/model.c:358-394) calls one operator
- * after the other.  With the switch on (default; environment NVLLM_DECODE_CHAIN=0 turns it off
- * at start-up) transformer_batch runs ALL layers of a decode-sized step -- at most 64 tokens,
+ * after the other.  With the switch on (off by default; environment NVLLM_DECODE_CHAIN=1 turns it
+ * on at start-up) transformer_batch runs ALL layers of a decode-sized step -- at most 64 tokens,
  * fp16 KV pool, the whole model on this GPU, a model shape the library has a tiling for -- as one
  * kernel launch whose workgroups hand their tiles to each other through arrival counters, so that
  * the weights of the next projection are already travelling while the current one is reduced and
  * stored; every other step takes one launch per operator as before.  Results are identical either
  * way (same tiles, same summation order).  The one-launch form needs every CU of the GPU for
- * itself: two processes that drive the same GPU must turn it off.
+ * itself: two processes that drive the same GPU must leave it off.  Measured on MI355X it is
+ * no faster than the separate kernels (a hand-off through memory costs what a kernel boundary
+ * costs), which is why it is opt-in.
  * nvllm_decode_chain_launches() counts the steps that took the one-launch form. */
 void nvllm_set_decode_chain(int on);
 int  nvllm_get_decode_chain(void);
@@ -82,8 +84,11 @@ long nvllm_decode_chain_launches(void);
  * Same result as matmul() (ops.h; reference src/kernels/layers.c:44-67) for a `weight`
  * handle that load_model produced and at most 64 tokens with in_dim <= 8192: the re-packed
  * activations, the split-K partial tiles and the arrival counters live in a static
- * device array of the library (6.1 MiB per GPU, held until the process ends) instead of
- * buffers the library allocates on demand.  Calls no hipMalloc / hipFree.  The library
+ * device array of the library (10.1 MiB per GPU, held until the process ends) instead of
+ * buffers the library allocates on demand.  Calls no hipMalloc / hipFree.  (The same K split
+ * as matmul(), hence the same bits, as long as the split's partial tiles fit 8 MiB of that
+ * array -- every split matmul() picks on a 256-CU GPU does; a split that does not fit is
+ * dropped, the result then agrees to rounding only.)  The library
  * must already be initialised (init_ops()).  Enqueues on nvllm_stream() and returns
  * without synchronising, like matmul().  All calls on one GPU share the one array:
  * calls that overlap on a GPU race.

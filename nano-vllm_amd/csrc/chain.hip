@@ -6,9 +6,18 @@
 // bytes arrive, and at the end a reduction, an epilogue and a store drain during which nothing
 // streams from HBM anywhere on the chip.  Weights, block tables and every K/V page but the newest
 // depend on nothing the step computes, so here a workgroup requests the first ring of its NEXT
-// tile's weights as soon as the K loop of its current tile has ended -- they travel while the
-// current tile is reduced, stored and handed over -- and attention requests its first pages before
-// the projection that produces q has finished.
+// tile's weights as soon as it has handed its current tile over -- they travel while the other
+// workgroups finish theirs -- and attention requests its first pages before the projection that
+// produces q has finished.
+//
+// What it buys (measured on MI355X, in-kernel clock stamps, tools/chain_stamps.py).  The overlap
+// happens -- the first ring of a tile has landed before the last workgroup of the previous phase
+// has drained its stores -- but a hand-off through memory costs what a kernel boundary costs: the
+// phase ends when its SLOWEST workgroup has stored (3 to 5 us behind the median), detecting that
+// takes another 1 to 2 us, and issuing a ring holds a wave for its bytes / ~50 GB/s.  TinyLlama-1.1B
+// at 64 rows: 70 us per layer here against 65 us as five kernels; the 42M shape at 32 rows: 0.28 ms
+// per step against 0.27.  The switch is therefore OFF unless asked for (NVLLM_DECODE_CHAIN=1 or
+// nvllm_set_decode_chain); the results are the same bits either way.
 //
 // How.  A grid of one 512-thread workgroup per CU runs, per layer, five phases with the work
 // decompositions of the separate kernels (gemm_tile.h, attn_tile.h; workgroup b takes tile b of
@@ -19,8 +28,9 @@
 // then loads past its vector cache (sc1).  All waits are bounded: a workgroup that waits longer
 // than a fifth of a second marks the step faulty, stops waiting and finishes, so the launch always
 // ends.  Static tile assignment needs every workgroup resident at once, which a census at the
-// start checks before anything is written; if it fails (another process holds CUs) the launch
-// reports it and the host runs the step's layers as separate kernels instead.
+// start checks before anything is written; if it fails (another process holds CUs) no workgroup
+// writes anything, the launch reports it in its status word and the pass ends with a fatal error
+// that names the switch (collect_pass in model.hip).
 #include "attn_tile.h"
 #include "gemm_tile.h"
 
@@ -288,21 +298,9 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
     for (int l = 0; l < n_layers; l++) {
         // ---------------------------------------------------------------- q, k, v (+ RoPE, K/V rows into the pool)
         h8_t ww[S::W_RW][S::W_NBW];
-        Attn16Wave<S::HD, 2, 4, true> aw;
-        bool att_started = false;
         {
             const int tid = chain_opaque_v((int)threadIdx.x);
             KArgs k = chain_kargs();
-            // this layer's attention: the first pages are requested now if none of them can change in this launch
-            AttnKArgs ak = karg(&k->att);
-            ak.layer_off = (long)l * k->layer_stride;
-            aw.setup(ak, (unsigned)(on_a ? b : 0), wave & 3, tid & 63, k->fresh_rule, run);
-            if (att_wave && aw.start_is_stable()) {
-                aw.start();
-                att_started = true;
-            } else {
-                aw.clear_ring();
-            }
             const ChainProj g = karg(&k->qkv);
             const ChainTile t = chain_tile(g, b, S::Q_TB, k->Tb);
             GemmArgs p = chain_gemm_args(k, g, k->layers[l].qkv, k->a16_x);
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             if (l > 0) chain_wait(k, chain_counter(k, l - 1, PH_DN), PH_DN, t.mask, s_word);
             bool wrote = false;
             if (t.on)
-                wrote = gemm_tile<S::Q_NBW, S::Q_TB, CH_NW, S::Q_RW, 2, GemmEpilogue::ROPE_KV, typename S::KVT, true, true>(
+                wrote = gemm_tile<S::Q_NBW, S::Q_TB, CH_NW, S::Q_RW, 2, GemmEpilogue::ROPE_KV, typename S::KVT, true, 1>(
                     p, t.ix, lds_dyn, wq, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_QKV), wrote, t.tb_lo, t.tb_hi);
             CHAIN_STAMP_END(k, l, PH_QKV);
@@ -328,9 +326,19 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             const ChainProj gw = karg(&k->wo);
             const ChainTile tw = chain_tile(gw, b, S::W_TB, k->Tb);
             const GemmArgs pw = chain_gemm_args(k, gw, k->layers[l].wo, k->a16_att);
-            // the output projection's weights: the waves that take no part in attention request theirs now,
-            // the others after their page loop
-            if (wave >= 4) gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, tw.ix, ww, tid, tw.on);
+            // the first pages are requested before the q/k/v projection has finished, if none of them can
+            // change in this launch
+            Attn16Wave<S::HD, 2, 4, true> aw;
+            bool att_started = false;
+            AttnKArgs ak = karg(&k->att);
+            ak.layer_off = (long)l * k->layer_stride;
+            aw.setup(ak, (unsigned)(on_a ? b : 0), wave & 3, tid & 63, k->fresh_rule, run);
+            if (att_wave && aw.start_is_stable()) {
+                aw.start();
+                att_started = true;
+            } else {
+                aw.clear_ring();
+            }
             chain_wait(k, chain_counter(k, l, PH_QKV), PH_QKV, ma, s_word);
 #ifdef NVLLM_STAMPS
             unsigned long long* const st = k->stamps ? k->stamps + ((size_t)(l * CH_PHASES + PH_ATT) * gridDim.x + b) * 8 : nullptr;
@@ -347,7 +355,6 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
 #ifdef NVLLM_STAMPS
             if (st && threadIdx.x == 0) st[3] = chain_clock();
 #endif
-            if (wave < 4) gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, tw.ix, ww, tid, tw.on);
             if (att_wave) aw.deposit(lds_dyn, wave);
             __syncthreads();
             if (att_wave) aw.merge(lds_dyn, wave);
@@ -358,6 +365,8 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
 #ifdef NVLLM_STAMPS
             if (st && threadIdx.x == 0) st[7] = chain_clock();
 #endif
+            // the output projection's weights travel while the other items finish
+            gemm_tile_prefetch<S::W_NBW, CH_NW, S::W_RW>(pw, tw.ix, ww, tid, tw.on);
         }
         h8_t wg[S::G_RW][S::G_NBW], wd[S::D_RW][S::D_NBW];
         // ---------------------------------------------------------------- x += att . wo^T; x * gain -> tiles
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             bool wrote = false;
             h8_t wg_new[S::G_RW][S::G_NBW];
             if (t.on)
-                wrote = gemm_tile<S::W_NBW, S::W_TB, CH_NW, S::W_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, ww, [](int) {}, tid);
+                wrote = gemm_tile<S::W_NBW, S::W_TB, CH_NW, S::W_RW, 2, GemmEpilogue::RESID_A16, float, true, 1>(p, t.ix, lds_dyn, ww, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_WO), wrote, t.tb_lo, t.tb_hi);
             CHAIN_STAMP_END(k, l, PH_WO);
             // the next tile's weights travel while the other workgroups finish theirs
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             bool wrote = false;
             h8_t wd_new[S::D_RW][S::D_NBW];
             if (t.on)
-                wrote = gemm_tile<S::G_NBW, S::G_TB, CH_NW, S::G_RW, 2, GemmEpilogue::SWIGLU_A16, float, true, true>(p, t.ix, lds_dyn, wg, [](int) {}, tid);
+                wrote = gemm_tile<S::G_NBW, S::G_TB, CH_NW, S::G_RW, 2, GemmEpilogue::SWIGLU_A16, float, true, 1>(p, t.ix, lds_dyn, wg, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_GU), wrote, t.tb_lo, t.tb_hi);
             CHAIN_STAMP_END(k, l, PH_GU);
             gemm_tile_prefetch<S::D_NBW, CH_NW, S::D_RW>(pn, tn.ix, wd_new, tid, tn.on);
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
             bool wrote = false;
             h8_t wq_new[S::Q_RW][S::Q_NBW];
             if (t.on)
-                wrote = gemm_tile<S::D_NBW, S::D_TB, CH_NW, S::D_RW, 2, GemmEpilogue::RESID_A16, float, true, true>(p, t.ix, lds_dyn, wd, [](int) {}, tid);
+                wrote = gemm_tile<S::D_NBW, S::D_TB, CH_NW, S::D_RW, 2, GemmEpilogue::RESID_A16, float, true, 1>(p, t.ix, lds_dyn, wd, [](int) {}, tid);
             chain_publish(chain_counter(k, l, PH_DN), wrote, t.tb_lo, t.tb_hi);
             CHAIN_STAMP_END(k, l, PH_DN);
             gemm_tile_prefetch<S::Q_NBW, CH_NW, S::Q_RW>(pn, tn.ix, wq_new, tid, more && tn.on);
@@ -502,7 +511,7 @@ extern "C" void nvllm_debug_set_chain_stamps(unsigned long long* buf) { g_chain_
 static int g_chain_on = -1;   // -1: not decided yet (the environment decides at first use)
 static long g_chain_launches = 0;
 int chain_enabled() {
-    if (g_chain_on < 0) g_chain_on = getenv("NVLLM_DECODE_CHAIN") ? (atoi(getenv("NVLLM_DECODE_CHAIN")) != 0) : 1;
+    if (g_chain_on < 0) g_chain_on = getenv("NVLLM_DECODE_CHAIN") ? (atoi(getenv("NVLLM_DECODE_CHAIN")) != 0) : 0;
     return g_chain_on;
 }
 extern "C" void nvllm_set_decode_chain(int on) { g_chain_on = on != 0; }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     h8_t w[NVLLM_RW][NBW];
     const TileIdx ix{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x};
-    gemm_tile<NBW, TB, NW, NVLLM_RW, NVLLM_RA, EPI, KVT, false, false>(p, ix, lds_dyn, w, [](int) {}, (int)threadIdx.x);
+    gemm_tile<NBW, TB, NW, NVLLM_RW, NVLLM_RA, EPI, KVT, false, 0>(p, ix, lds_dyn, w, [](int) {}, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ launch

@@ -79,11 +79,14 @@ __device__ __forceinline__ void copy_tile_to_lds(const __half* lane_src, unsigne
 // The same copy for the steady state of the K loop: M0 is written and left (nothing else in
 // this kernel reads it: the compiler sets M0 itself right before any use of its own), the LDS address is a wave-uniform
 // base plus a constant.
+// The address is summed by the compiler (its own scalar add, whose condition-code write it accounts
+// for); the statement itself only moves it into M0, which touches no condition code.
 template <int OFS>
 __device__ __forceinline__ void copy_tile_to_lds_at(const __half* lane_src, unsigned lds_base) {
-    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+    const unsigned dst = lds_base + OFS;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :
-                 : "v"(lane_src), "s"(lds_base), "n"(OFS)
+                 : "v"(lane_src), "s"(dst)
                  : "memory");
 }
 

@@ -134,9 +134,11 @@ __device__ __forceinline__ void gemm_tile_prefetch(const GemmArgs& p, const Tile
 // K slice that was not the last to arrive).  `slot_free(r)` is called exactly once for every r in
 // [0, RW), as soon as the wave will not load ring entry r again for this tile -- inside the K loop,
 // spread over its last RW steps: the place to start loads for later work, a few at a time.
-template <int NBW, int TB, int NW, int RW, int RA, int EPI, typename KVT, bool COH, bool PRE, typename Hook>
+// PRE: 0 = the tile requests its first RW K-steps of weights itself; 1 = the caller has (gemm_tile_prefetch);
+// 2 = the caller says at run time (`prefetched`, uniform over the workgroup).
+template <int NBW, int TB, int NW, int RW, int RA, int EPI, typename KVT, bool COH, int PRE, typename Hook>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, unsigned char* lds_dyn, h8_t (&w)[RW][NBW],
-                                          Hook&& slot_free, const int tid) {
+                                          Hook&& slot_free, const int tid, const bool prefetched = true) {
     static_assert(NBW % 2 == 0, "row blocks are reduced in pairs");
     static_assert(RW % RA == 0, "the activation ring must divide the weight ring");
     constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
@@ -203,7 +205,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     // Loads are issued only for steps that exist (wave-uniform branches): a clamped
     // re-load of the last tile would be real HBM traffic, since streamed weights are
     // loaded non-temporally and do not stay in L2.
-    if constexpr (!PRE) {
+    if (PRE == 0 || (PRE == 2 && !prefetched)) {
 #pragma unroll
         for (int s = 0; s < RW; s++)
             if (s < nsteps) {

@@ -84,7 +84,22 @@ static bool f32_file_fits_fp16(FILE* f, long start, const std::vector<std::pair<
     return ok;
 }
 
-// State of the most recent forward pass, for sample() and nvllm_last_argmax().
+// What sample() and nvllm_last_argmax() may look at: the pass most recently COLLECTED.  A pass's view
+// is put together when it is enqueued and becomes current only when it is collected, all fields at once,
+// so between nvllm_forward_enqueue(n + 1) and its collect the callers still see pass n, consistently.
+struct PassView {
+    const int* argmax = nullptr;        // page-locked indices, one per output row
+    int outputs = 0;
+    const float* logits_host = nullptr; // RunState.logits of the pass: rows there NAME its outputs
+    const float* logits_dev = nullptr;  // its logits in HBM -- a workspace the NEXT enqueued pass overwrites
+    int vocab = 0;
+    long ticket = -1;
+    // tensor parallelism: the pass left only this rank's vocabulary slice (arg-max hand-off);
+    // sample() with a temperature gathers the full rows when it needs them
+    const float* tp_local = nullptr;
+    bool tp_full_valid = true;
+    int tp_slice = 0;
+};
 // Arg-max indices of the passes in flight: a small ring of page-locked arrays, each with the
 // event recorded behind the copy that fills it.  A pass enqueued with nvllm_forward_enqueue owns
 // slot (ticket % PASS_RING) until it is collected; transformer_batch collects at once.
@@ -94,22 +109,12 @@ struct PassSlot {
     int cap = 0;
     hipEvent_t ev = nullptr;
     long ticket = -1;
-    int outputs = 0;
     bool chained = false;   // the pass ran its layers as one launch: host[outputs] is that launch's status word
+    PassView view;
 };
 static PassSlot g_pass[PASS_RING];
 static long g_next_ticket = 0;
-static int* g_argmax_host = nullptr;   // the most recent collected pass's indices (one of the ring's arrays)
-static int g_last_outputs = 0;
-static const float* g_last_logits_host = nullptr;
-static const float* g_last_logits_dev = nullptr;
-static int g_last_vocab = 0;
-static long g_pass_serial = 0;         // bumped by every forward pass
-// tensor parallelism: the last pass left only this rank's vocabulary slice (arg-max hand-off);
-// sample() with a temperature gathers the full rows when it needs them
-static const float* g_tp_local = nullptr;
-static bool g_tp_full_valid = true;
-static int g_tp_slice = 0;
+static PassView g_seen;                // the most recently collected pass
 
 static void read_exact(FILE* f, void* dst, size_t bytes, const char* what) {
     if (fread(dst, 1, bytes, f) != bytes) {
@@ -127,12 +132,15 @@ static void tp_gather_logits(float* full, const float* local, int rows, int slic
 }
 
 // End of a forward pass: the copies that carry its results to the host are enqueued behind its
-// kernels and an event behind them; returns the pass's ticket.
-static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V, bool chained = false) {
+// kernels and an event behind them; returns the pass's ticket.  `view` arrives with the tensor-parallel
+// fields set.
+static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V, PassView view, bool chained = false) {
     const long ticket = g_next_ticket++;
     PassSlot& slot = g_pass[ticket % PASS_RING];
     if (slot.ticket >= 0) NVLLM_FATAL("forward pass %ld was never collected: at most %d passes may be in flight", slot.ticket, PASS_RING);
-    if (B > slot.cap) {
+    // the slot's previous pass (PASS_RING passes ago) ends here: nobody may go on reading its indices
+    if (g_seen.argmax == slot.host) g_seen = PassView{};
+    if (B + 1 > slot.cap) {
         if (slot.host) HIP_CHECK(hipHostFree(slot.host));
         slot.cap = B + 256;
         HIP_CHECK(hipHostMalloc((void**)&slot.host, (size_t)slot.cap * sizeof(int), hipHostMallocDefault));
@@ -146,31 +154,33 @@ static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int 
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipEventRecord(slot.ev, stream));
     slot.ticket = ticket;
-    slot.outputs = B;
-    g_last_outputs = B;
-    g_pass_serial++;
-    g_last_logits_host = s->logits;
-    g_last_logits_dev = d_logits;
-    g_last_vocab = V;
+    view.argmax = slot.host;
+    view.outputs = B;
+    view.logits_host = s->logits;
+    view.logits_dev = d_logits;
+    view.vocab = V;
+    view.ticket = ticket;
+    slot.view = view;
     return ticket;
 }
 
-// Wait for a pass's results; its indices stay readable at the returned address until the slot's
-// next use (PASS_RING passes later).
+// Wait for a pass's results and make it the pass sample() and nvllm_last_argmax() answer for; its
+// indices stay readable at the returned address until the slot's next use (PASS_RING passes later).
 static const int* collect_pass(long ticket, int* num_outputs) {
     PassSlot& slot = g_pass[ticket % PASS_RING];
-    if (slot.ticket != ticket) NVLLM_FATAL("forward pass %ld is not in flight", ticket);
+    if (ticket < 0 || slot.ticket != ticket) NVLLM_FATAL("forward pass %ld is not in flight", ticket);
     HIP_CHECK(hipEventSynchronize(slot.ev));
-    if (slot.chained && slot.host[slot.outputs] != 1) {
-        const int st = slot.host[slot.outputs];
+    const int B = slot.view.outputs;
+    if (slot.chained && slot.host[B] != 1) {
+        const int st = slot.host[B];
         NVLLM_FATAL("the one-launch decode step did not complete (status %d: %s); set NVLLM_DECODE_CHAIN=0 to run the layers as separate kernels",
                     st, (st & 4) ? "a workgroup waited for a hand-off longer than 0.2 s"
                                  : (st & 2) ? "not all of its workgroups were resident at once -- is another process using this GPU?"
                                             : "it never started");
     }
     slot.ticket = -1;
-    if (num_outputs) *num_outputs = slot.outputs;
-    g_argmax_host = slot.host;
+    if (num_outputs) *num_outputs = B;
+    g_seen = slot.view;
     return slot.host;
 }
 
@@ -576,8 +586,8 @@ void free_run_state(RunState* s) {
     device_free(s->q); device_free(s->k); device_free(s->v); device_free(s->att); device_free(s->logits);
     if (s->key_cache) device_free(s->key_cache);
     if (s->value_cache) device_free(s->value_cache);
+    if (g_seen.logits_host == s->logits) g_seen.logits_host = nullptr;   // its rows name nothing any more
     memset(s, 0, sizeof *s);
-    g_last_logits_host = nullptr;
 }
 
 void transformer(int* tokens, int num_tokens, int pos, Config* p, RunState* s, Weights* w, BlockTable* bt) {
@@ -635,8 +645,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         if (st.d_tok_src) launch_patch_tokens(st.d_tokens, st.d_tok_src, d_argmax, T);
         forward_f32(st, T, B, p, s, w, pool, rope, d_logits);
         launch_argmax(d_argmax, d_logits, B, V);
-        g_tp_full_valid = true;
-        return finish_pass(s, d_logits, d_argmax, B, V);
+        return finish_pass(s, d_logits, d_argmax, B, V, PassView{});
     }
 
     // One launch for all layers (chain.hip) when the step fits it: a decode-sized batch on an fp16 page pool,
@@ -754,7 +763,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     GemmEpilogue e5;
     e5.kind = GemmEpilogue::F32;
     e5.ss_in = ss_head; e5.ss_tiles = ssn; e5.d_in = D; e5.eps = eps;
-    g_tp_full_valid = true;
+    PassView view;
     // no K split for the classifier (tens of thousands of rows fill the chip); from 112 output rows the
     // launcher may take the dense-tile kernel instead (0 = its own choice)
     const int head_split = B >= 112 ? 0 : 1;
@@ -776,22 +785,22 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
             e5.ldo = ld;
             launch_gemm(wh, m->head, mine, a16_head, B, e5, head_split, PC_GEMM_HEAD);
         }
-        g_tp_local = local;
-        g_tp_slice = ld;
+        view.tp_local = local;
+        view.tp_slice = ld;
         if (rt().logits_mode == NVLLM_LOGITS_ARGMAX) {
             float2* pairs = (float2*)(local + (((size_t)B * ld + 1) & ~(size_t)1));
             launch_argmax_pairs(pairs, local, B, mine, ld, base);
             float2* all = (float2*)ws_get(WS_TP_GATHER, (size_t)W * B * sizeof(float2));
             tp_allgather((const float*)pairs, (float*)all, 2 * (size_t)B);
             launch_argmax_merge(d_argmax, all, W, B);
-            g_tp_full_valid = false;   // d_logits was not produced; sample() gathers it if it needs rows
+            view.tp_full_valid = false;   // d_logits was not produced; sample() gathers it if it needs rows
         } else {
             tp_gather_logits(d_logits, local, B, ld, V);
             launch_argmax(d_argmax, d_logits, B, V);
         }
     }
 
-    return finish_pass(s, d_logits, d_argmax, B, V, chained);
+    return finish_pass(s, d_logits, d_argmax, B, V, view, chained);
 }
 
 void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,
@@ -843,8 +852,8 @@ int nvllm_argmax_rows(int* out, const float* logits, int num_rows, int vocab_siz
 }
 
 const int* nvllm_last_argmax(int* num_outputs) {
-    if (num_outputs) *num_outputs = g_last_outputs;
-    return g_argmax_host;
+    if (num_outputs) *num_outputs = g_seen.outputs;
+    return g_seen.argmax;
 }
 
 // ------------------------------------------------------------------ sampler
@@ -863,12 +872,26 @@ void build_sampler(Sampler* s, int vocab_size, float temperature, float topp, un
 // receives the few candidates of each row, sorts them with the reference's comparator
 // and walks the cumulative sums with the reference's libc rand() coin.
 constexpr int SAMPLE_CAP = 1024;          // candidates kept per row; fuller rows take the whole-row path
-static long g_prep_serial = -1;           // pass whose rows are prepared ...
-static float g_prep_temp = 0.f, g_prep_topp = 0.f;   // ... with these settings
-static float* g_probs_dev = nullptr;      // [rows, V] of the prepared pass (workspace)
-static ProbIndex* g_cand_host = nullptr;  // pinned [cap_rows, SAMPLE_CAP]
-static int* g_count_host = nullptr;       // pinned [cap_rows]
-static int g_cand_rows = 0;
+// One prepared set of rows: probabilities in HBM, the nucleus candidates of every row in page-locked
+// memory, and (when something needs whole rows on the host) the probabilities there too.  Two sets:
+// all rows of a pass, prepared together, and a lone row the caller brought.  Buffers only ever grow.
+struct Prepared {
+    float* probs_dev = nullptr;       // [rows, V] (workspace)
+    ProbIndex* cand_host = nullptr;   // pinned [cand_rows, SAMPLE_CAP]
+    int* count_host = nullptr;        // pinned [cand_rows]
+    int cand_rows = 0;
+    float* probs_host = nullptr;      // pinned [rows, V], filled on demand ...
+    size_t probs_host_cap = 0;
+    bool probs_on_host = false;       // ... for the current set
+    int rows = 0, V = 0;
+    long ticket = -1;                 // pass whose rows are prepared (-1: none) ...
+    float temp = 0.f, topp = 0.f;     // ... with these settings ...
+    bool host_rows = false;           // ... from the rows in RunState.logits (else from the logits in HBM)
+};
+static Prepared g_prep_pass, g_prep_lone;
+// logits mode HOST: the rows of the pass as they stood in RunState.logits when they were uploaded together
+static float* g_rows_snapshot = nullptr;   // pinned
+static size_t g_rows_snapshot_cap = 0;
 
 static int by_prob_desc(const void* a, const void* b) {   // sampler.c:29-35
     const float pa = ((const ProbIndex*)a)->prob, pb = ((const ProbIndex*)b)->prob;
@@ -898,67 +921,78 @@ static int nucleus_pick(ProbIndex* c, int n, float topp, float coin) {
     return c[last].index;
 }
 
-static void prepare_rows(const float* logits_dev, int rows, int V, float temperature, float topp) {
-    const bool nucleus = topp > 0.f && topp < 1.f;
-    const float cutoff = nucleus ? (1.0f - topp) / (float)(V - 1) : -1.0f;   // sampler.c:47
-    if (rows > g_cand_rows) {
-        if (g_cand_host) HIP_CHECK(hipHostFree(g_cand_host));
-        if (g_count_host) HIP_CHECK(hipHostFree(g_count_host));
-        g_cand_rows = rows + 64;
-        HIP_CHECK(hipHostMalloc((void**)&g_cand_host, (size_t)g_cand_rows * SAMPLE_CAP * sizeof(ProbIndex), hipHostMallocDefault));
-        HIP_CHECK(hipHostMalloc((void**)&g_count_host, (size_t)g_cand_rows * sizeof(int), hipHostMallocDefault));
+// all rows' probabilities -> page-locked host memory, one copy
+static void fetch_probs(Prepared& pr) {
+    const size_t n = (size_t)pr.rows * pr.V;
+    if (n > pr.probs_host_cap) {
+        if (pr.probs_host) HIP_CHECK(hipHostFree(pr.probs_host));
+        pr.probs_host_cap = n + n / 4;
+        HIP_CHECK(hipHostMalloc((void**)&pr.probs_host, pr.probs_host_cap * sizeof(float), hipHostMallocDefault));
     }
-    g_probs_dev = (float*)ws_get(WS_MISC, (size_t)rows * V * sizeof(float));
-    char* scratch = (char*)ws_get(WS_MISC2, (size_t)rows * (SAMPLE_CAP * sizeof(ProbIndex) + sizeof(int)) + 256);
-    ProbIndex* cand_dev = (ProbIndex*)scratch;
-    int* count_dev = (int*)(scratch + (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex));
-    launch_sample_prep(g_probs_dev, logits_dev, rows, V, temperature, cutoff, cand_dev, SAMPLE_CAP, count_dev);
-    if (nucleus) {
-        HIP_CHECK(hipMemcpyAsync(g_count_host, count_dev, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, rt().stream));
-        HIP_CHECK(hipMemcpyAsync(g_cand_host, cand_dev, (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex), hipMemcpyDeviceToHost, rt().stream));
-    }
+    HIP_CHECK(hipMemcpyAsync(pr.probs_host, pr.probs_dev, n * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
     HIP_CHECK(hipStreamSynchronize(rt().stream));
+    pr.probs_on_host = true;
 }
 
-// one prepared row -> token, with the reference's coin.  `host_probs`: the row's probabilities when
-// the caller already has them on the host (else they are fetched if the whole row is needed).
-static int pick_from_row(Sampler* s, int row, int V, const float* host_probs) {
+// `probs_ws` / `cand_ws`: the workspace slots that hold this set's device side.
+static void prepare_rows(Prepared& pr, WsSlot probs_ws, WsSlot cand_ws, const float* logits_dev, int rows, int V,
+                         float temperature, float topp, bool want_probs_on_host) {
+    const bool nucleus = topp > 0.f && topp < 1.f;
+    const float cutoff = nucleus ? (1.0f - topp) / (float)(V - 1) : -1.0f;   // sampler.c:47
+    if (rows > pr.cand_rows) {
+        if (pr.cand_host) HIP_CHECK(hipHostFree(pr.cand_host));
+        if (pr.count_host) HIP_CHECK(hipHostFree(pr.count_host));
+        pr.cand_rows = rows + 64;
+        HIP_CHECK(hipHostMalloc((void**)&pr.cand_host, (size_t)pr.cand_rows * SAMPLE_CAP * sizeof(ProbIndex), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&pr.count_host, (size_t)pr.cand_rows * sizeof(int), hipHostMallocDefault));
+    }
+    pr.probs_dev = (float*)ws_get(probs_ws, (size_t)rows * V * sizeof(float));
+    char* scratch = (char*)ws_get(cand_ws, (size_t)rows * (SAMPLE_CAP * sizeof(ProbIndex) + sizeof(int)) + 256);
+    ProbIndex* cand_dev = (ProbIndex*)scratch;
+    int* count_dev = (int*)(scratch + (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex));
+    launch_sample_prep(pr.probs_dev, logits_dev, rows, V, temperature, cutoff, cand_dev, SAMPLE_CAP, count_dev);
+    if (nucleus) {
+        HIP_CHECK(hipMemcpyAsync(pr.count_host, count_dev, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, rt().stream));
+        HIP_CHECK(hipMemcpyAsync(pr.cand_host, cand_dev, (size_t)rows * SAMPLE_CAP * sizeof(ProbIndex), hipMemcpyDeviceToHost, rt().stream));
+    }
+    pr.rows = rows;
+    pr.V = V;
+    pr.temp = temperature;
+    pr.topp = topp;
+    pr.probs_on_host = false;
+    // plain sampling walks whole rows on the host (sampler.c:126-134): they travel now, together
+    if (want_probs_on_host || !nucleus) fetch_probs(pr);
+    else HIP_CHECK(hipStreamSynchronize(rt().stream));
+}
+
+// one prepared row -> token, with the reference's coin
+static int pick_from_row(Sampler* s, Prepared& pr, int row) {
     const float coin = (float)rand() / (float)RAND_MAX;   // sampler.c:124
     const bool nucleus = s->topp > 0.f && s->topp < 1.f;
-    if (nucleus && g_count_host[row] <= SAMPLE_CAP)
-        return nucleus_pick(g_cand_host + (size_t)row * SAMPLE_CAP, g_count_host[row], s->topp, coin);
+    if (nucleus && pr.count_host[row] <= SAMPLE_CAP)
+        return nucleus_pick(pr.cand_host + (size_t)row * SAMPLE_CAP, pr.count_host[row], s->topp, coin);
     // whole-row path: plain sampling (sampler.c:126-134), or a nucleus too wide for the candidate buffer
-    float* fetched = nullptr;
-    const float* pr = host_probs;
-    if (!pr) {
-        fetched = (float*)malloc((size_t)V * sizeof(float));
-        HIP_CHECK(hipMemcpyAsync(fetched, g_probs_dev + (size_t)row * V, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
-        HIP_CHECK(hipStreamSynchronize(rt().stream));
-        pr = fetched;
-    }
-    int tok = V - 1;
+    // (then every row of the set comes over, once: its neighbours are likely as wide)
+    if (!pr.probs_on_host) fetch_probs(pr);
+    const float* p = pr.probs_host + (size_t)row * pr.V;
+    const int V = pr.V;
     if (!nucleus) {
         float cdf = 0.0f;
         for (int i = 0; i < V; i++) {
-            cdf += pr[i];
-            if (coin < cdf) {
-                tok = i;
-                break;
-            }
+            cdf += p[i];
+            if (coin < cdf) return i;
         }
-    } else {
-        const float cutoff = (1.0f - s->topp) / (float)(V - 1);
-        int n = 0;
-        for (int i = 0; i < V; i++)
-            if (pr[i] >= cutoff) {
-                s->probindex[n].index = i;
-                s->probindex[n].prob = pr[i];
-                n++;
-            }
-        tok = nucleus_pick(s->probindex, n, s->topp, coin);
+        return V - 1;
     }
-    free(fetched);
-    return tok;
+    const float cutoff = (1.0f - s->topp) / (float)(V - 1);
+    int n = 0;
+    for (int i = 0; i < V; i++)
+        if (p[i] >= cutoff) {
+            s->probindex[n].index = i;
+            s->probindex[n].prob = p[i];
+            n++;
+        }
+    return nucleus_pick(s->probindex, n, s->topp, coin);
 }
 
 // Reference src/sampler.c:84-140.  Which memory answers depends on the hand-off mode:
@@ -967,17 +1001,18 @@ static int pick_from_row(Sampler* s, int row, int V, const float* host_probs) {
 //                        stands, and with a temperature it is rewritten to probabilities, like the
 //                        reference's in-place softmax (sampler.c:100-121).
 //   NVLLM_LOGITS_ARGMAX  RunState.logits was never filled; a pointer to row k of it only NAMES output k
-//                        of the most recent pass, whose logits are still in HBM.
+//                        of the most recently collected pass, whose logits are still in HBM.
 int sample(Sampler* s, float* logits) {
     ensure_init();
     const int V = s->vocab_size;
-    int row = -1;   // output row of the most recent forward pass that `logits` names, if any
-    if (rt().logits_mode == NVLLM_LOGITS_ARGMAX && g_last_logits_host && V == g_last_vocab && logits >= g_last_logits_host) {
-        const size_t d = (size_t)(logits - g_last_logits_host);
-        if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_last_outputs) row = (int)(d / (size_t)V);
+    int row = -1;   // output row of the most recently collected forward pass that `logits` points at, if any
+    if (g_seen.logits_host && V == g_seen.vocab && logits >= g_seen.logits_host) {
+        const size_t d = (size_t)(logits - g_seen.logits_host);
+        if (d % (size_t)V == 0 && d / (size_t)V < (size_t)g_seen.outputs) row = (int)(d / (size_t)V);
     }
+    const bool named = row >= 0 && rt().logits_mode == NVLLM_LOGITS_ARGMAX;   // the pointer only names the row
     if (s->temperature == 0.0f) {
-        if (row >= 0) return g_argmax_host[row];   // the arg-max the GPU already computed
+        if (named) return g_seen.argmax[row];   // the arg-max the GPU already computed
         // sampler.c:86-97 on the caller's row: the strict '>' scan from index 0 ends on the first
         // index that attains the maximum.  Two passes the compiler can vectorise: the maximum (a
         // NaN never wins a '>' and an initial NaN is never displaced, as in the reference), then
@@ -988,28 +1023,54 @@ int sample(Sampler* s, float* logits) {
             if (logits[i] == top) return i;
         return 0;   // logits[0] is NaN: the reference's scan never leaves index 0
     }
-    // temperature > 0: softmax and the nucleus filter run on the GPU
-    if (row >= 0) {
-        if (!g_tp_full_valid) {   // the logits are vocabulary slices on the ranks: every rank makes this call
-            tp_gather_logits(const_cast<float*>(g_last_logits_dev), g_tp_local, g_last_outputs, g_tp_slice, V);
-            g_tp_full_valid = true;
+    // temperature > 0: softmax and the nucleus filter run on the GPU, for all rows of the pass at once
+    Prepared& pp = g_prep_pass;
+    const bool fresh = pp.ticket == g_seen.ticket && pp.temp == s->temperature && pp.topp == s->topp && pp.host_rows == !named;
+    if (named) {
+        if (!fresh) {
+            // the logits live in a workspace that the next pass's classifier overwrites
+            if (g_seen.ticket != g_next_ticket - 1)
+                NVLLM_FATAL("sample(): pass %ld's logits are gone, pass %ld was enqueued since; sample a pass's rows before the next nvllm_forward_enqueue",
+                            g_seen.ticket, g_next_ticket - 1);
+            if (!g_seen.tp_full_valid) {   // the logits are vocabulary slices on the ranks: every rank makes this call
+                tp_gather_logits(const_cast<float*>(g_seen.logits_dev), g_seen.tp_local, g_seen.outputs, g_seen.tp_slice, V);
+                g_seen.tp_full_valid = true;
+            }
+            prepare_rows(pp, WS_MISC, WS_MISC2, g_seen.logits_dev, g_seen.outputs, V, s->temperature, s->topp, false);
+            pp.ticket = g_seen.ticket;
+            pp.host_rows = false;
         }
-        if (g_prep_serial != g_pass_serial || g_prep_temp != s->temperature || g_prep_topp != s->topp) {
-            prepare_rows(g_last_logits_dev, g_last_outputs, V, s->temperature, s->topp);   // all rows of the pass at once
-            g_prep_serial = g_pass_serial;
-            g_prep_temp = s->temperature;
-            g_prep_topp = s->topp;
-        }
-        return pick_from_row(s, row, V, nullptr);
+        return pick_from_row(s, pp, row);
     }
-    // a host row: upload it, prepare it alone, hand the probabilities back in place
+    if (row >= 0 && g_seen.outputs > 1) {
+        // HOST mode, a row of the pass: the first such call uploads ALL its rows as they stand now and
+        // prepares them together; a row the caller has changed since then is handled alone, below.
+        const size_t n = (size_t)g_seen.outputs * V;
+        if (!fresh) {
+            if (n > g_rows_snapshot_cap) {
+                if (g_rows_snapshot) HIP_CHECK(hipHostFree(g_rows_snapshot));
+                g_rows_snapshot_cap = n + n / 4;
+                HIP_CHECK(hipHostMalloc((void**)&g_rows_snapshot, g_rows_snapshot_cap * sizeof(float), hipHostMallocDefault));
+            }
+            memcpy(g_rows_snapshot, g_seen.logits_host, n * sizeof(float));
+            float* dev = (float*)ws_get(WS_SAMPLE_ROWS, n * sizeof(float));
+            HIP_CHECK(hipMemcpyAsync(dev, g_rows_snapshot, n * sizeof(float), hipMemcpyHostToDevice, rt().stream));
+            prepare_rows(pp, WS_SAMPLE_PROBS, WS_SAMPLE_CAND, dev, g_seen.outputs, V, s->temperature, s->topp, true);
+            pp.ticket = g_seen.ticket;
+            pp.host_rows = true;
+        }
+        if (memcmp(logits, g_rows_snapshot + (size_t)row * V, (size_t)V * sizeof(float)) == 0) {
+            memcpy(logits, pp.probs_host + (size_t)row * V, (size_t)V * sizeof(float));   // in place, like sampler.c:100-121
+            return pick_from_row(s, pp, row);
+        }
+    }
+    // a lone host row: upload it, prepare it, hand the probabilities back in place
+    Prepared& pl = g_prep_lone;
     float* dev = (float*)ws_get(WS_SAMPLE, (size_t)V * sizeof(float));
     HIP_CHECK(hipMemcpyAsync(dev, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice, rt().stream));
-    prepare_rows(dev, 1, V, s->temperature, s->topp);
-    g_prep_serial = -1;   // the prepared buffers no longer describe the last pass
-    HIP_CHECK(hipMemcpyAsync(logits, g_probs_dev, (size_t)V * sizeof(float), hipMemcpyDeviceToHost, rt().stream));
-    HIP_CHECK(hipStreamSynchronize(rt().stream));
-    return pick_from_row(s, 0, V, logits);
+    prepare_rows(pl, WS_SAMPLE_PROBS1, WS_SAMPLE_CAND1, dev, 1, V, s->temperature, s->topp, true);
+    memcpy(logits, pl.probs_host, (size_t)V * sizeof(float));
+    return pick_from_row(s, pl, 0);
 }
 
 }  // extern "C"

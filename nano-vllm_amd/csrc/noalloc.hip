@@ -23,7 +23,11 @@ constexpr int NOALLOC_COUNTERS = 16384;
 constexpr size_t NOALLOC_COUNTER_BYTES = (size_t)NOALLOC_COUNTERS * sizeof(unsigned);                   // 64 KiB
 constexpr size_t NOALLOC_A16_BYTES = (size_t)(NOALLOC_MAX_TOKENS / 16) * (NOALLOC_MAX_IN_DIM / 32) * 2 *
                                      TILE_HALVES * sizeof(__half);                                      // 2 MiB
-constexpr size_t NOALLOC_SLAB_BYTES = (size_t)4 << 20;                                                  // 4 MiB
+// Partial tiles of a K split.  The split matmul() picks by itself makes at most about 1.5 workgroups
+// per CU with at most 16 KiB of partial tile each: 6 MiB on 256 CUs.  Should a split not fit all the
+// same (a GPU with more CUs), the launcher drops it and every workgroup sweeps the whole K: same
+// result to rounding, not to the bit, and slower.
+constexpr size_t NOALLOC_SLAB_BYTES = (size_t)8 << 20;                                                  // 8 MiB
 constexpr size_t NOALLOC_BYTES = NOALLOC_COUNTER_BYTES + NOALLOC_A16_BYTES + NOALLOC_SLAB_BYTES;
 
 // In host code this name is only a stand-in for the symbol, not a device address: the
@@ -52,6 +56,7 @@ extern "C" int nvllm_matmul_noalloc(float* out, const float* in, const float* we
         fprintf(stderr, "nvllm_matmul_noalloc: call init_ops() first (initialisation allocates, this call must not)\n");
         return -1;
     }
+    ensure_init();   // initialised already: this only binds the calling thread to the library's GPU
     unsigned char* base = g_scratch_ptr[rt().device];
     if (!base) {
         fprintf(stderr, "nvllm_matmul_noalloc: no scratch address for device %d\n", rt().device);

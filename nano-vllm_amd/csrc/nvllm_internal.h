@@ -114,7 +114,12 @@ enum WsSlot {
     WS_STEP,        // per-call integer arrays (tokens, pos, seq ids, tables ...)
     WS_MISC,
     WS_MISC2,
-    WS_SAMPLE,      // a logits row handed to sample() that is not part of the last forward pass
+    WS_SAMPLE,      // a logits row handed to sample() that is not part of the last forward pass ...
+    WS_SAMPLE_PROBS1,   // ... its probabilities and nucleus candidates
+    WS_SAMPLE_CAND1,
+    WS_SAMPLE_ROWS,     // logits mode HOST: all rows of a pass, uploaded again for sample() with a temperature
+    WS_SAMPLE_PROBS,
+    WS_SAMPLE_CAND,
     WS_TP_LOCAL,    // tensor parallelism: this rank's slice of the logits / its arg-max pairs
     WS_TP_GATHER,   // ... and what the ranks gathered
     WS_CHAIN_SYNC,  // arrival counters of the one-launch decode step

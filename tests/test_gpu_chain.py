@@ -102,9 +102,9 @@ def test_64_decode_rows_one_launch_equals_separate_kernels_and_the_oracle(hip, o
 
 def test_one_launch_at_contexts_beyond_1000(hip, wide):
     """The attention phase over ~66 pages per item, with the first pages requested before the
-    q/k/v projection has finished: 64 sequences continue at positions 1040-1056 over a pool filled
-    with the separate kernels' own prefill of three of them (the others over zero pages), three
-    layers deep.  Same bits as the separate kernels."""
+    q/k/v projection has finished: 64 sequences continue at positions 1040-1056 with their prompts
+    skipped (the earlier pool rows are whatever the pool holds: zeros), three layers deep.  Same
+    bits as the separate kernels."""
     path, shape = wide
     prompts = synth.make_requests(64, 1060, 1060, shape.vocab_size, seed=32)
 

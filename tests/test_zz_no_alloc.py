@@ -12,13 +12,25 @@ from nvllm_amd import capi
 pytestmark = pytest.mark.gpu
 
 
+def _free_device_bytes():
+    """hipMemGetInfo through the HIP runtime the library itself is linked against."""
+    rtl = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert rtl.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
 def _both(hip, handle, x, K, N):
     T = x.shape[0]
     dx = hip.to_device(x)
     d_ref, d_new = hip.empty_device(T * N * 4), hip.to_device(np.full((T, N), np.nan, np.float32))
     hip.matmul(d_ref, dx, handle, T, K, N)
+    hip.device_sync()
+    before = _free_device_bytes()
     rc = hip.nvllm_matmul_noalloc(d_new, dx, handle, T, K, N)
     assert rc == 0
+    hip.device_sync()
+    assert _free_device_bytes() == before      # nothing was allocated (or freed) on the GPU
     want, got = hip.to_host(d_ref, (T, N)), hip.to_host(d_new, (T, N))
     for p in (dx, d_ref, d_new):
         hip.free(p)
@@ -47,6 +59,13 @@ def test_matmul_noalloc_matches_matmul_twice_in_a_row(hip, tmp_models):
         for handle, x, K, N in ((lw.w_down, x_big, F, D), (lw.wq, x_small, D, D)):
             want, got = _both(hip, handle, x, K, N)
             np.testing.assert_array_equal(got, want)
+        # a second call on another host thread (HIP's current device is per thread)
+        import threading
+        res = {}
+        th = threading.Thread(target=lambda: res.update(r=_both(hip, lw.w_down, x_big, F, D)))
+        th.start()
+        th.join()
+        np.testing.assert_array_equal(res["r"][1], res["r"][0])
         # limits and bad handles are refused with an error code, nothing is enqueued
         dx, do = hip.to_device(np.zeros((65, D), np.float32)), hip.empty_device(65 * D * 4)
         assert hip.nvllm_matmul_noalloc(do, dx, lw.wq, 65, D, D) == -3
@@ -54,5 +73,22 @@ def test_matmul_noalloc_matches_matmul_twice_in_a_row(hip, tmp_models):
         assert hip.nvllm_matmul_noalloc(do, dx, dx, 4, D, D) == -2
         hip.free(dx)
         hip.free(do)
+    finally:
+        hip.nvllm_free_model(C.byref(w))
+
+
+def test_matmul_noalloc_keeps_the_k_split_of_a_wide_projection(hip, tmp_models):
+    """170 tiles x 2 K slices x 16 KiB of partial tile = 5.3 MiB: the widest partial-tile slab a
+    self-chosen split makes on 256 CUs still fits the static array, so the bits stay matmul()'s."""
+    path, shape = tmp_models("tiny", seed=73, dim=4096, hidden_dim=10880, n_layers=1, n_heads=32, n_kv_heads=4,
+                             vocab_size=64, max_seq_len=128)
+    w, cfg = capi.Weights(), capi.Config()
+    hip.load_model(C.byref(w), C.byref(cfg), path.encode())
+    try:
+        r = np.random.Generator(np.random.PCG64(74))
+        for T in (64, 7):
+            x = r.standard_normal((T, cfg.dim)).astype(np.float32)
+            want, got = _both(hip, w.layers[0].w_gate, x, cfg.dim, cfg.hidden_dim)
+            np.testing.assert_array_equal(got, want)
     finally:
         hip.nvllm_free_model(C.byref(w))

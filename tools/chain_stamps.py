@@ -57,6 +57,7 @@ def main():
     buf = C.c_void_p()
     assert lib.device_malloc(C.byref(buf), nwords * 8) == 0
     zeros = np.zeros(nwords, np.uint64)
+    lib.nvllm_set_decode_chain(1)
     before = lib.nvllm_decode_chain_launches()
     for rep in range(4):
         lib.device_memcpy(buf, zeros.ctypes.data, zeros.nbytes, capi.HOST_TO_DEVICE)
