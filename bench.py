@@ -185,7 +185,16 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
     lib.nvllm_set_device(env.device_index())
     lib.nvllm_set_kv_elem_bytes(args.kv_bytes)
     lib.nvllm_set_logits_mode(0 if args.logits_host else 1)   # default: only token ids return to the host
-    if args.tp and not getattr(run_gpu, "_tp_up", False):
+    if args.tp_slice and not getattr(run_gpu, "_tp_up", False):
+        # ONE rank's share of a model split over `world` ranks, alone on this GPU: the exchange is a callback
+        # that does nothing (partial sums stay partial -- the arithmetic and the bytes of the step are those
+        # of the rank, its results mean nothing), so the time is the rank's compute without any exchange
+        run_gpu._tp_up = True
+        rank, world = args.tp_slice
+        run_gpu._noop = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
+        if lib.nvllm_tp_init_custom(rank, world, run_gpu._noop, None) != 0:
+            raise SystemExit("bench: tensor-parallel slice setup failed")
+    elif args.tp and not getattr(run_gpu, "_tp_up", False):
         run_gpu._tp_up = True
         # one RCCL communicator over all ranks, owned by the library: its all-reduces run on the
         # library's stream.  (With one rank the same code path runs, the sums have one term.)
@@ -238,7 +247,8 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
     st = eng.stats()
     assert st.decode_step_tokens == (args.warmup + args.steps) * B, "a timed step was not a pure decode step"
     ctx_mid = [c + args.warmup + args.steps // 2 for c in ctx0]
-    step_bytes = algorithmic_bytes_per_decode_step(shape, B, ctx_mid, args.kv_bytes, env.world if args.tp else 1)
+    step_bytes = algorithmic_bytes_per_decode_step(shape, B, ctx_mid, args.kv_bytes,
+                                                   args.tp_slice[1] if args.tp_slice else (env.world if args.tp else 1))
 
     # ---- per-kernel durations from HIP events on the library stream (same workload,
     #      the steps right after the timed region; events would perturb the timing)
@@ -314,6 +324,9 @@ def main():
     ap.add_argument("--tp", action="store_true",
                     help="the ranks hold ONE model, split by heads / MLP columns, with RCCL all-reduces (default workload: "
                          "llama2-7b shape, batch 128, 128-token prompts)")
+    ap.add_argument("--tp-slice", default=None, metavar="R/W",
+                    help="with --tp on ONE GPU: time rank R's share of a model split over W ranks with a no-op exchange "
+                         "(what a rank of a W-GPU run computes between its all-reduces; results are meaningless)")
     ap.add_argument("--model", default=None)
     ap.add_argument("--batch", type=int, default=None, help="concurrent sequences per GPU (per model under --tp)")
     ap.add_argument("--prompt-len", type=int, default=None)
@@ -330,6 +343,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8, help="decode steps of the CPU baseline leg (about 1.7 s each on 16 cores); 0 disables it")
     ap.add_argument("--model-dir", default=os.environ.get("NVLLM_MODEL_DIR", "/tmp"))
     args = ap.parse_args()
+    if args.tp_slice:
+        if not args.tp or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("bench: --tp-slice goes with --tp in a single process")
+        args.tp_slice = tuple(int(v) for v in args.tp_slice.split("/"))
     defaults = (("llama2-7b", 128, 128, 512) if args.tp else ("tinyllama-1.1b", 64, 1024, 2048))
     for name, val in zip(("model", "batch", "prompt_len", "max_seq_len"), defaults):
         if getattr(args, name) is None:
@@ -371,7 +388,7 @@ def main():
         roofline, by_kernel = None, {}
         if r["prof"]:
             # group the timing classes by kernel symbol: all projections are one kernel
-            sym = lambda cls: ("k_gemm" if cls.startswith("gemm") else
+            sym = lambda cls: ("k_gemm" if cls.startswith("gemm") else "k_decode_chain" if cls == "decode_chain" else
                                ("k_paged_attn16" if args.kv_bytes == 2 else "k_paged_attn") if cls == "attn" else
                                {"attn_combine": "k_attn_combine", "argmax": "k_argmax", "embed": "k_embed_prescale"}.get(cls, cls))
             for cls, d in r["prof"].items():
@@ -403,7 +420,9 @@ def main():
             cpu = cpu_baseline(args, shape, model_path, r["ctx"])
         step_gbs = r["step_bytes"] / (ms_per_step * 1e-3) / 1e9
         line = {
-            "metric": (f"decode tokens/sec (node) + % HBM peak, Llama-2-7B-shape TP={N} batch {B}" if args.tp else
+            "metric": (f"decode tokens/sec of rank {args.tp_slice[0]}'s share alone, exchange excluded, Llama-2-7B-shape TP={args.tp_slice[1]} batch {B}"
+                       if args.tp_slice else
+                       f"decode tokens/sec (node) + % HBM peak, Llama-2-7B-shape TP={N} batch {B}" if args.tp else
                        "decode tokens/sec (node) + % HBM peak, TinyLlama-1.1B paged batch 64"),
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if args.tp else "weak",
@@ -413,7 +432,7 @@ def main():
                                    f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
                                    f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
                                    f"mean context {r['ctx']} in the timed region",
-                       "batch_per_gpu": B, "parallelism": f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes,
+                       "batch_per_gpu": B, "parallelism": f"one rank of tp{args.tp_slice[1]}, no exchange" if args.tp_slice else f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes,
                        "result_handoff": "logits rows to host (PCIe-inclusive)" if args.logits_host else "token ids only"},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,
@@ -423,7 +442,7 @@ def main():
                          "frac_of_peak": round(step_gbs / HBM_PEAK_GBS, 4)},
             "forward_ms_per_step": round(r["forward_ms"], 4),
             "prefill_tokens_per_s": round(prefill_tps, 1),
-            "prefill_roofline": prefill_roofline(shape, prefill_tps, env.world if args.tp else 1),
+            "prefill_roofline": None if args.tp_slice else prefill_roofline(shape, prefill_tps, env.world if args.tp else 1),
             "kernels": {k: {"launches": v["launches"], "avg_us": round(v["total_ms"] / v["launches"] * 1e3, 2),
                             "GBps": round(v["bytes"] / max(v["total_ms"], 1e-9) / 1e6, 1)} for k, v in r["prof"].items()},
         }

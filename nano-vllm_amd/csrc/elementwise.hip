@@ -549,6 +549,11 @@ void launch_argmax(int* out, const float* logits, int B, int V) {
     ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
     NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, V, (float2*)nullptr, 0);
 }
+void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, ld, (float2*)nullptr, 0);
+}
 void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * n_valid * 4.0, 0);
@@ -567,6 +572,36 @@ __global__ __launch_bounds__(256) void k_argmax_merge(int* __restrict__ out, con
     }
     out[b] = (int)best.y;
 }
+// The classifier's per-tile pairs [tile][ld] (gemm_tile.h, F32 epilogue): tiles own ascending index
+// ranges; an index below zero marks a tile that saw nothing but NaN for the row.  One wave per row.
+__global__ __launch_bounds__(256) void k_argmax_tiles(int* __restrict__ out, const float2* __restrict__ pairs, int n_tiles, int B, int ld) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    float best = -INFINITY, bi = -1.0f;
+    for (int i = lane; i < n_tiles; i += 64) {
+        const float2 c = pairs[(size_t)i * ld + b];
+        if (c.y >= 0.f && (c.x > best || bi < 0.f || (c.x == best && c.y < bi))) {
+            best = c.x;
+            bi = c.y;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0.f && (ov > best || bi < 0.f || (ov == best && oi < bi))) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) out[b] = bi < 0.f ? 0 : (int)bi;   // (nothing but NaN: the reference's scan stays at index 0)
+}
+void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld) {
+    if (B <= 0) return;
+    ProfScope ps(PC_ARGMAX, (double)n_tiles * B * 8.0, 0);
+    NVLLM_LAUNCH(k_argmax_tiles, dim3(cdiv(B, 4)), dim3(256), 0, out, pairs, n_tiles, B, ld);
+}
+
 void launch_argmax_merge(int* out, const float2* pairs, int W, int B) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)W * B * 8.0, 0);

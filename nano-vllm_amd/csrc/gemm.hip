@@ -242,8 +242,12 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
             g_stamp_next++;
         }
 #endif
-        ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
-        launch_gemm_prefill(a);
+        a.e.amax_pairs = nullptr;   // the dense-tile kernel does not emit pairs: the rows are scanned afterwards
+        {
+            ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
+            launch_gemm_prefill(a);
+        }
+        if (epi.kind == GemmEpilogue::F32 && epi.amax_out) launch_argmax_ld(epi.amax_out, epi.out, T, N, epi.ldo);
         return a.ksplit;
     }
     const GemmPlan pl = gemm_plan(N, w.K, T, epi.kind, force_ksplit, max_counters, wsp ? wsp->slab_bytes : 0);
@@ -266,6 +270,9 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         a.slab = wsp ? wsp->slab : (float*)ws_get(WS_SLAB, need);
     }
     const dim3 grid(tiles_n, ks, tiles_t);
+    const bool amax = epi.kind == GemmEpilogue::F32 && epi.amax_out != nullptr;
+    if (amax && (!epi.amax_pairs || epi.amax_ld < T)) NVLLM_FATAL("fused arg-max needs a pair buffer of at least %d rows per tile", T);
+    {
     ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
     const bool kv16 = epi.kind == GemmEpilogue::ROPE_KV && epi.kv_elem_bytes == 2;
     if (nbw == 6) {
@@ -284,6 +291,9 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         else if (TB == 2) launch_tb<GEMM_NBW, 2, float>(a, grid);
         else launch_tb<GEMM_NBW, 4, float>(a, grid);
     }
+    }
+    // the tiles' (maximum, index) pairs -> one index per row (tiles that are grid padding wrote nothing)
+    if (amax) launch_argmax_tiles(epi.amax_out, epi.amax_pairs, cdiv(a.NB, nbw), T, epi.amax_ld);
     return ks;
 }
 

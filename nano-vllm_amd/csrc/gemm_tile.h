@@ -436,6 +436,21 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                             if (n + r < p.N) o[r] = y[r];
                     }
                 }
+                if (ep.amax_pairs != nullptr) {
+                    // this item's four outputs: first index of their maximum (a NaN never wins, -inf may)
+                    float bv = -INFINITY, bi = -1.0f;
+                    if (live) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (n + r < p.N && (y[r] > bv || (bi < 0.f && y[r] == bv))) {
+                                bv = y[r];
+                                bi = (float)(n + r);
+                            }
+                    }
+                    // (the partial tiles in `red` have been consumed: two barriers back)
+                    float2* am = reinterpret_cast<float2*>(&red[0][0][0][0]);
+                    am[((2 * h + i) * 4 + (l >> 4)) * (TB * 16) + tl] = make_float2(bv, bi);
+                }
             } else if (EPI == GemmEpilogue::SWIGLU_A16) {
                 if (i == 0 && live) {
                     const f4_t u = red[0][1][j][l];
@@ -503,6 +518,21 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                     }
                 }
             }
+        }
+    }
+    if (EPI == GemmEpilogue::F32 && ep.amax_pairs != nullptr) {
+        // per token, over the tile's features in ascending order: the first maximum
+        __syncthreads();
+        if (tid < TB * 16) {
+            const float2* am = reinterpret_cast<const float2*>(&red[0][0][0][0]);
+            float2 best = am[tid];
+#pragma unroll
+            for (int s = 1; s < NBW * 4; s++) {
+                const float2 c = am[s * (TB * 16) + tid];
+                if (c.y >= 0.f && (c.x > best.x || best.y < 0.f)) best = c;
+            }
+            const int t = tb0 * 16 + tid;
+            if (t < p.T) ep.amax_pairs[(size_t)ix.x * ep.amax_ld + t] = best;
         }
     }
     if (EPI == GemmEpilogue::RESID_A16) {

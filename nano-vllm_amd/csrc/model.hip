@@ -771,8 +771,12 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         WeightEntry wh{m->head, V, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
         e5.out = d_logits;
         e5.ldo = V;
+        // the classifier's tiles also report their (maximum, index) pairs: the greedy token comes from
+        // a merge of those instead of a second pass over the logits
+        e5.amax_out = d_argmax;
+        e5.amax_ld = (B + 63) & ~63;
+        e5.amax_pairs = (float2*)ws_get(WS_AMAX_PAIRS, (size_t)cdiv(V, 32) * e5.amax_ld * sizeof(float2));
         launch_gemm(wh, m->head, V, a16_head, B, e5, head_split, PC_GEMM_HEAD);
-        launch_argmax(d_argmax, d_logits, B, V);
     } else {
         // this rank's vocabulary rows; then either one (max, index) pair per row from every rank,
         // or the slices themselves when full rows are wanted

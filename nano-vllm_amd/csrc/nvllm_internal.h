@@ -123,6 +123,7 @@ enum WsSlot {
     WS_TP_LOCAL,    // tensor parallelism: this rank's slice of the logits / its arg-max pairs
     WS_TP_GATHER,   // ... and what the ranks gathered
     WS_CHAIN_SYNC,  // arrival counters of the one-launch decode step
+    WS_AMAX_PAIRS,  // the classifier tiles' (maximum, index) pairs
     WS_COUNT
 };
 void* ws_get(WsSlot slot, size_t bytes);
@@ -194,6 +195,12 @@ struct GemmEpilogue {
     // F32: out[t, ldo]
     float* out = nullptr;
     int ldo = 0;
+    // F32, optional: also the first index of each row's maximum over all N outputs (the sampler's greedy
+    // rule, reference sampler.c:86-97) -> amax_out[t].  Every tile leaves one (maximum, index) pair per
+    // token in amax_pairs[tile][amax_ld] (room for cdiv(N, 32) tiles), a small launch merges them.
+    int* amax_out = nullptr;
+    float2* amax_pairs = nullptr;
+    int amax_ld = 0;
     // SWIGLU_A16 / RESID_A16: fp16 hi/lo tiles for the next projection
     __half* a16_out = nullptr;
     int Kb_out = 0;
@@ -361,6 +368,8 @@ void launch_argmax(int* out, const float* logits, int B, int V);
 // gathered vocabulary slices [rank][row][Vl] into logits rows [row][V]
 void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base);
 void launch_argmax_merge(int* out, const float2* pairs, int W, int B);
+void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld);   // rows `ld` floats apart
+void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld);
 void launch_logits_unshard(float* full, const float* parts, int W, int B, int Vl, int V);
 // probs = softmax(logits / temperature) per row; cutoff >= 0 also compacts the entries >= cutoff, in
 // index order, into cand[row][0..cap) and counts them (count may exceed cap: the row did not fit)

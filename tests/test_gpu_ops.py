@@ -291,6 +291,47 @@ def test_fp16_pool_attention_over_prefill_chunks(hip, oracle, hd, H, KVH):
         po.close()
 
 
+@pytest.mark.parametrize("kv_bytes", [2, 4])
+@pytest.mark.parametrize("lo,hi", [(1040, 1100), (3900, 3960)])
+def test_attention_at_the_benchmark_shape(hip, oracle, kv_bytes, lo, hi):
+    """The decode batch the benchmark times, as one operator call: 64 sequences, one new token each, at
+    contexts of 1,040 to 1,100 keys (65 to 69 pages per item) and of about 3,900; 32 query heads over
+    4 kv heads of 64 -- 256 items of four waves, one per CU.  fp16 pages and the reference's fp32 rows."""
+    hd, H, KVH, n_seqs = 64, 32, 4, 64
+    r = rng(lo + kv_bytes)
+    L, bs, S = 1, 16, 4096
+    ctx = [int(c) for c in r.integers(lo, hi + 1, size=n_seqs)]
+    ctx[:4] = [lo, hi, lo + 15, lo + 16]
+    maxb = S // bs
+    nb = sum((c + bs - 1) // bs for c in ctx) + 7
+    hip.nvllm_set_kv_elem_bytes(kv_bytes)
+    try:
+        ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+        perm = r.permutation(nb)
+        cur = 0
+        for s, c in enumerate(ctx):
+            need = (c + bs - 1) // bs
+            blocks = perm[cur:cur + need].tolist()
+            cur += need
+            ph.set_table(s, blocks)
+            po.set_table(s, blocks)
+        h16 = lambda a: a.astype(np.float16).astype(np.float32)
+        kfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        vfill = h16(r.standard_normal(ph.elems()).astype(np.float32))
+        ph.fill(kfill, vfill)
+        po.fill(kfill, vfill)
+        pos = [c - 1 for c in ctx]
+        sid = list(range(n_seqs))
+        q = r.standard_normal((n_seqs, H * hd)).astype(np.float32)
+        want = util.op_paged_attention_batch(oracle, po, q, 0, pos, sid, S, H, KVH, hd)
+        got = util.op_paged_attention_batch(hip, ph, q, 0, pos, sid, S, H, KVH, hd)
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.abs(want).max() + 2e-6)
+    finally:
+        hip.nvllm_set_kv_elem_bytes(4)
+        ph.close()
+        po.close()
+
+
 def test_kv_write_table_too_small_stops(hip, oracle, capfd):
     """Reference attention.c:159-162: the first token whose logical block is not in
     the table prints and ends the call; later tokens are not written."""

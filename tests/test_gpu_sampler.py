@@ -130,3 +130,52 @@ def test_sample_reads_the_host_row_as_the_caller_left_it(hip, oracle, tmp_models
         e.close()
     finally:
         hip.nvllm_set_logits_mode(0)
+
+
+def _classifier_with_repeating_rows(src, dst, shape, period=37, nan_row=3):
+    """Copy of a model file whose classifier rows repeat with `period` (every logits row then attains
+    its maximum at several indices, in every 64-feature tile) and hold one row of NaN."""
+    import shutil
+    shutil.copyfile(src, dst)
+    V, D = shape.vocab_size, shape.dim
+    with open(dst, "r+b") as f:
+        f.seek(-V * D * 2, 2)
+        head = np.frombuffer(f.read(V * D * 2), np.float16).reshape(V, D).copy()
+        head[:] = head[np.arange(V) % period]
+        head[nan_row] = np.nan
+        f.seek(-V * D * 2, 2)
+        f.write(head.tobytes())
+
+
+@pytest.mark.parametrize("n_seqs", [5, 130])
+def test_greedy_pick_from_the_classifier_tiles_takes_the_first_maximum(hip, oracle, tmp_models, tmp_path, n_seqs):
+    """The greedy token comes from (maximum, index) pairs that the classifier's tiles leave behind, merged
+    per row (130 rows: the dense-tile classifier, rows scanned afterwards).  With classifier rows that repeat
+    every 37 indices each maximum is attained about V / 37 times, inside every tile and across tiles: the
+    pick must be the lowest index (sampler.c:86-97), a NaN logit never wins."""
+    src, shape = tmp_models("tiny", seed=5, vocab_size=1000 if n_seqs > 5 else 777, max_seq_len=256)
+    path = str(tmp_path / "ties.bin")
+    _classifier_with_repeating_rows(src, path, shape)
+    prompts = synth.make_requests(n_seqs, 1, 1 if n_seqs > 5 else 9, shape.vocab_size, seed=6)
+    kw = dict(n_new=6, chunk_size=64, temperature=0.0, max_steps=100, collect_logits=True)
+    from tests import util
+    got = util.run_engine(hip, path, prompts, **kw)                              # rows to the host as well
+    hip.nvllm_set_logits_mode(1)
+    try:
+        got2 = util.run_engine(hip, path, prompts, **{k: v for k, v in kw.items() if k != "collect_logits"})
+    finally:
+        hip.nvllm_set_logits_mode(0)
+    for sg in got["steps"]:
+        rows = sg["logits"]
+        assert np.isnan(rows[:, 3]).all()
+        first = [int(np.flatnonzero(r == np.nanmax(r))[0]) for r in rows]
+        # the ties are there (index 3 is NaN: that class's first finite repeat is 3 + 37)
+        assert all((i < 37 or i == 40) and np.count_nonzero(r == np.nanmax(r)) > 1 for i, r in zip(first, rows))
+        np.testing.assert_array_equal(sg["sampled"], first)
+    for a, b in zip(got2["histories"], got["histories"]):       # the pick from the tiles' pairs
+        np.testing.assert_array_equal(a, b)
+    # the CPU checker agrees wherever its own rows tie exactly (its row loop may round repeated rows differently)
+    want = util.run_engine(oracle, path, prompts, **kw)
+    if all(int(t) < 37 or int(t) == 40 for s in want["steps"] for t in s["sampled"]):
+        for a, b in zip(got["histories"], want["histories"]):
+            np.testing.assert_array_equal(a, b)
