@@ -265,8 +265,9 @@ def test_unmodified_reference_driver_runs_on_the_gpu(tmp_path):
     """The reference's own main() -- its scheduler loop, tokenizer, sampler, dashboards, compiled
     unmodified (oracle/_ref/nano_vllm_hip, built where /root/reference exists) and linked with
     libnvllm_hip.so -- against the reference's own CPU binary on the same model and tokenizer
-    files: the generated text of both sequences must be byte-identical (2-sequence demo, paged,
-    chunked prefill, greedy)."""
+    files: the whole transcript (every scheduler step, the dashboards, the generated text of both
+    sequences) must be identical but for the wall-clock line (2-sequence demo, paged, chunked
+    prefill, greedy)."""
     import os
     import subprocess
     ref_dir = checkers.REF_DIR
@@ -283,7 +284,11 @@ def test_unmodified_reference_driver_runs_on_the_gpu(tmp_path):
         assert r.returncode == 0, (name, r.stderr[-2000:])
         out = r.stdout
         assert b"=== Final Generated Sequences ===" in out, (name, out[-2000:])
-        tail = out[out.index(b"=== Final Generated Sequences ==="):]
-        outs[name] = tail[:tail.index(b"\n=================================")]
-    assert b"[Seq 0]: " in outs["ref"] and b"[Seq 1]: " in outs["ref"]
-    assert outs["hip"] == outs["ref"]
+        # the whole transcript -- loader report, scheduler log of every step, block dashboards, generated
+        # text -- except the wall-clock line (src/main.c:443)
+        outs[name] = [ln for ln in out.decode("utf-8", "replace").splitlines() if not ln.startswith("Time: ")]
+    assert any(ln.startswith("[Seq 0]: ") for ln in outs["ref"]) and any(ln.startswith("[Seq 1]: ") for ln in outs["ref"])
+    if outs["hip"] != outs["ref"]:
+        import difflib
+        diff = list(difflib.unified_diff(outs["ref"], outs["hip"], "reference", "hip", lineterm="", n=1))
+        raise AssertionError("transcripts differ:\n" + "\n".join(diff[:60]))

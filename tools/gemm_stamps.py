@@ -73,9 +73,13 @@ def main():
             cols.append(f"{k}: {np.median(v):5.2f} ({v.min():5.2f}..{v.max():5.2f})" if v.size else f"{k}: -")
         print(f"{names[i]:10s} {int(live.sum()):4d} | " + "  ".join(cols))
         # per-workgroup durations of the phases (median over workgroups)
+        # (a stamp a workgroup never wrote -- those that leave before the K split is closed write no 5 and 6 -- is
+        # zero in the buffer: it takes no part in any figure)
+        rel = np.where(s > 0, rel, np.nan)
         d = np.diff(rel, axis=1)
-        print(f"{'':15s} | phase medians: issue {np.median(d[:,0]):.2f}  first-data {np.median(d[:,1]):.2f}  loop {np.median(d[:,2]):.2f}  "
-              f"lds-sum {np.median(d[:,3]):.2f}  close {np.median(d[:,4]):.2f}  epilogue+drain {np.median(d[:,5]):.2f}  | wg life {np.median(rel[:,6]-rel[:,0]):.2f}")
+        med = lambda a: f"{np.nanmedian(a):.2f}" if np.isfinite(a).any() else "-"
+        print(f"{'':15s} | phase medians: issue {med(d[:,0])}  first-data {med(d[:,1])}  loop {med(d[:,2])}  "
+              f"lds-sum {med(d[:,3])}  close {med(d[:,4])}  epilogue+drain {med(d[:,5])}  | wg life {med(rel[:,6]-rel[:,0])}")
     eng.close()
     # ---- the same projection four times in a row on the same weights: from the second launch on
     # they come from the caches (an upper bound on what warming them ahead of a launch could buy)
@@ -100,10 +104,10 @@ def main():
             sl = st[i]
             live = sl[:, 0] > 0
             sl = sl[live].astype(np.float64)
-            rel = (sl - sl[:, 0].min()) / 100.0
-            med = [float(np.median(rel[:, k])) for k in range(7)]
+            rel = np.where(sl > 0, (sl - sl[:, 0].min()) / 100.0, np.nan)      # unwritten stamps take no part
+            med = [float(np.nanmedian(rel[:, k])) if np.isfinite(rel[:, k]).any() else float("nan") for k in range(7)]
             print(f"matmul {name:7s} launch {i} wgs {int(live.sum()):3d} | " + "  ".join(f"{k}: {m:5.2f}" for k, m in enumerate(med))
-                  + f" | end {rel[:, 6].max():5.2f}")
+                  + f" | end {np.nanmax(rel):5.2f}")
         for q in (dx, do, big):
             lib.free(q)
 
