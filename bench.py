@@ -266,7 +266,7 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
                 prof[lib.nvllm_prof_name(c).decode()] = dict(launches=n.value, total_ms=ms.value,
                                                              bytes=by.value, flops=fl.value)
     hist = eng.history(0)[-4:].tolist()
-    forward_ms = st.decode_step_seconds / max(1, args.warmup + args.steps) * 1e3   # inside transformer_batch only
+    forward_ms = st.decode_step_seconds / max(1, args.warmup + args.steps) * 1e3   # host time spent enqueueing decode passes and waiting for their results (no sampling)
     eng.close()
     return dict(elapsed=elapsed, prefill_s=prefill_s, prefill_tokens=prefill_tokens, step_bytes=step_bytes,
                 prof=prof, ctx=int(np.mean(ctx_mid)), tail=hist, forward_ms=forward_ms)

@@ -202,10 +202,12 @@ typedef struct {
     long long prefill_tokens;   /* tokens forwarded by prefill chunks           */
     long long decode_tokens;    /* tokens forwarded by decode rows              */
     long long outputs;          /* sample() calls                               */
-    double forward_seconds;     /* wall time inside transformer_batch           */
+    double forward_seconds;     /* wall time inside transformer_batch; two-halves loop: enqueueing a pass
+                                   plus waiting for its results (sampling excluded)                     */
     double sample_seconds;      /* wall time inside sample()                    */
-    double prefill_step_seconds;/* forward time of steps containing any prefill */
-    double decode_step_seconds; /* forward time of pure-decode steps            */
+    double prefill_step_seconds;/* forward time of passes containing any prefill (a pass's wait counts
+                                   for that pass, whichever step collects it)                           */
+    double decode_step_seconds; /* forward time of pure-decode passes           */
     long long decode_step_tokens;/* tokens forwarded by pure-decode steps       */
     long long prefill_step_tokens;
 } NvllmEngineStats;

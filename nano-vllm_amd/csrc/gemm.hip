@@ -71,6 +71,9 @@ int gemm_pick_ksplit(int N, int K, int T) {
     int ks = (target_wgs + groups / 2) / groups;      // aim for a few hundred workgroups
     const int ks_max = Kb / GEMM_NW > 0 ? Kb / GEMM_NW : 1;  // at least one K-step per wave
     if (ks > ks_max) ks = ks_max;
+    // never a few workgroups more than CUs: they would run alone in a second round (86 groups x 3 slices
+    // = 258 workgroups took as long as two rounds)
+    if (ks > 1 && groups * ks > rt().num_cus) ks = rt().num_cus / groups;
     if (ks < 1) ks = 1;
     const int per = cdiv(Kb, ks);
     return cdiv(Kb, per);

@@ -76,6 +76,7 @@ struct NvllmEngine {
     int pend_active;
     long pend_ticket;
     int pend_outputs;
+    int pend_prefill;      /* the pass in flight carries prompt tokens (its time counts as prefill time) */
     int* pend_seq;
     int* pend_hist_pos;
     int* row_of_seq;        /* per sequence: its output row in the pass in flight, or -1 */
@@ -160,7 +161,14 @@ NvllmEngine* nvllm_engine_create(const char* model_path, int n_seqs, const Nvllm
  * current tokens and complete the record of the last batch. */
 static void engine_flush(NvllmEngine* e) {
     if (!e->pend_active) return;
+    /* the wait for the pass belongs to the forward time of ITS class (prefill or decode), whichever step
+     * of the driver happens to collect it */
+    const double c0 = now_seconds();
     const int n = nvllm_forward_collect(e->pend_ticket, e->collected, e->n_seqs);
+    const double waited = now_seconds() - c0;
+    e->stats.forward_seconds += waited;
+    if (e->pend_prefill) e->stats.prefill_step_seconds += waited;
+    else e->stats.decode_step_seconds += waited;
     const int host_rows = nvllm_get_logits_mode() != NVLLM_LOGITS_ARGMAX;
     const RunState* st = e->pend_state ? &e->state2 : &e->state;
     e->seen_state = e->pend_state;
@@ -371,13 +379,14 @@ int nvllm_engine_step(NvllmEngine* e) {
             fprintf(stderr, "nvllm engine: the backend refused to enqueue the pass\n");
             exit(1);
         }
-        /* the pass before this one: its tokens also complete this batch's record */
+        const double t1 = now_seconds();   /* enqueue only: staging the batch and launching the kernels */
+        /* the pass before this one (its wait and its sampling are accounted for in engine_flush): its tokens
+         * also complete this batch's record */
         if (e->pend_active) {
             engine_flush(e);
             for (int t = 0; t < batch_count; t++)
                 if (e->batch_token_src[t] >= 0) e->batch_tokens[t] = e->collected[e->batch_token_src[t]];
         }
-        const double t1 = now_seconds();
         /* bookkeeping that does not need the token values (main.c:395-409) */
         for (int k = 0; k < output_count; k++) {
             const int sid = e->batch_seq_ids[e->batch_output_indices[k]];
@@ -393,6 +402,7 @@ int nvllm_engine_step(NvllmEngine* e) {
             }
         }
         e->pend_active = 1;
+        e->pend_prefill = any_prefill;
         e->pend_state = e->flip;
         e->flip ^= 1;
         e->pend_ticket = ticket;
