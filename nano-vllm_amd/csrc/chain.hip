@@ -230,6 +230,7 @@ __device__ __forceinline__ GemmArgs chain_gemm_args(KArgs k, const ChainProj& g,
     p.ksplit = g.ksplit;
     p.slab = k->slab;
     p.counters = k->tile_counters;
+    p.close_sc1 = 1;   // one workgroup per CU, slab from hipMalloc
 #ifdef NVLLM_STAMPS
     p.stamps = nullptr;
 #endif

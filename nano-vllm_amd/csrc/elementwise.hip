@@ -485,6 +485,8 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
     const float* row = logits + (size_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    // (the reference's scan starts from logits[0] and nothing displaces a NaN there: sampler.c:86-97)
+    const bool nan_at_zero = index_base == 0 && V > 0 && row[0] != row[0];
     auto take = [&](float v, int i) {
         if (v > best || (v == best && i < bi)) {
             best = v;
@@ -539,7 +541,11 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
                 bi = si[w];
             }
         // a row of -inf (or NaN in slot 0) leaves the scan at index 0 in the reference
-        const int idx = bi == 0x7fffffff ? 0 : bi;
+        int idx = bi == 0x7fffffff ? 0 : bi;
+        if (nan_at_zero) {   // wins every merge: +inf at index 0
+            best = INFINITY;
+            idx = 0;
+        }
         if (pairs) pairs[blockIdx.x] = make_float2(V > 0 ? best : -INFINITY, (float)(index_base + idx));
         else out[blockIdx.x] = idx;
     }

@@ -50,12 +50,12 @@ namespace nvllm {
 #endif
 
 // One workgroup = one tile (gemm_tile.h); weight ring of NVLLM_RW K-steps, activation ring of NVLLM_RA.
-template <int NBW, int TB, int NW, int EPI, typename KVT>
+template <int NBW, int TB, int NW, int EPI, typename KVT, int RW = NVLLM_RW>
 __global__ __launch_bounds__(NW * 64) void k_gemm(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    h8_t w[NVLLM_RW][NBW];
+    h8_t w[RW][NBW];
     const TileIdx ix{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x};
-    gemm_tile<NBW, TB, NW, NVLLM_RW, NVLLM_RA, EPI, KVT, false, 0>(p, ix, lds_dyn, w, [](int) {}, (int)threadIdx.x);
+    gemm_tile<NBW, TB, NW, RW, NVLLM_RA, EPI, KVT, false, 0>(p, ix, lds_dyn, w, [](int) {}, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ launch
@@ -98,17 +98,17 @@ constexpr int MAX_COUNTERS = 1 << 16;
 
 // One instantiation: its dynamic LDS is the waves' partial tiles (1 KiB per wave, row block and
 // token block); sizes beyond the 64 KiB default are enabled once.
-template <int NBW, int TB, int NW, int EPI, typename KVT>
+template <int NBW, int TB, int NW, int EPI, typename KVT, int RW = NVLLM_RW>
 static void launch_k(const GemmArgs& a, dim3 grid) {
     constexpr int shmem = gemm_tile_lds<NBW, TB, NW>();
     static_assert(shmem <= 160 * 1024, "partial tiles must fit the CU's LDS");
     static bool enabled = false;
     if (shmem > 64 * 1024 && !enabled) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<NBW, TB, NW, EPI, KVT>),
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<NBW, TB, NW, EPI, KVT, RW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
         enabled = true;
     }
-    NVLLM_LAUNCH((k_gemm<NBW, TB, NW, EPI, KVT>), grid, dim3(NW * 64), shmem, a);
+    NVLLM_LAUNCH((k_gemm<NBW, TB, NW, EPI, KVT, RW>), grid, dim3(NW * 64), shmem, a);
 }
 
 template <int NBW, int TB, typename KVT>
@@ -237,6 +237,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         a.kb_per_split = a.Kb;
         a.slab = nullptr;
         a.counters = g_counters;
+        a.close_sc1 = 0;
         if (wide_decode_k2 && T < pf_min_t) a.ksplit = 2;   // every tile's K in two (slab: the launcher's)
 #ifdef NVLLM_STAMPS
         a.stamps = nullptr;
@@ -273,6 +274,8 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
         a.slab = wsp ? wsp->slab : (float*)ws_get(WS_SLAB, need);
     }
     const dim3 grid(tiles_n, ks, tiles_t);
+    static const int sc1_env = getenv("NVLLM_GEMM_CLOSE_SC1") ? atoi(getenv("NVLLM_GEMM_CLOSE_SC1")) : 1;
+    a.close_sc1 = sc1_env && ks > 1 && !wsp && (long)tiles_n * ks * tiles_t <= rt().num_cus;
     const bool amax = epi.kind == GemmEpilogue::F32 && epi.amax_out != nullptr;
     if (amax && (!epi.amax_pairs || epi.amax_ld < T)) NVLLM_FATAL("fused arg-max needs a pair buffer of at least %d rows per tile", T);
     {

@@ -22,6 +22,8 @@ struct GemmArgs {
     int ksplit;
     float* slab;      // [tile][slice][round][item] float4
     unsigned* counters;
+    int close_sc1;    // K split: the closing workgroup loads the partials past the vector cache instead of invalidating it
+                      // (launches of at most one workgroup per CU over a hipMalloc slab)
     GemmEpilogue e;
 #ifdef NVLLM_STAMPS
     unsigned long long* stamps;   // diagnostic builds only: [workgroup][8] constant-rate clock readings

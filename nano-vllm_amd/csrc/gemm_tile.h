@@ -358,10 +358,19 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
             *s_ticket = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*s_ticket != (unsigned)p.ksplit - 1) return false;     // not the last slice of this tile
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
-        __syncthreads();
+        // The partials were stored write-through, every storing wave drained, and this workgroup's add came
+        // last (its returned value says so, read behind the barrier above).  With one workgroup per CU the
+        // partials may then be loaded past the vector cache (sc1) with no invalidate; otherwise an agent
+        // acquire comes first.
+        const bool past_l1 = p.close_sc1;
+        if (!past_l1) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
+            __syncthreads();
+        }
         const float* base = p.slab + (size_t)tile_id * p.ksplit * (ROUNDS * ITEMS * 4);
+        __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0,
+                                                                           p.ksplit * ROUNDS * ITEMS * 16, 0x00020000);
         // Every slab load of both rounds is issued before the first add: one round trip.
         // Slice indices past the end are clamped (a repeated load), not predicated, so the
         // loads stay unconditional; sums are taken in slice order.
@@ -379,7 +388,11 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int sl = min(s0 + u, p.ksplit - 1);
-                        part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
+                        if (past_l1)
+                            part[h][q][u] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                         rs_all, ((sl * ROUNDS + h) * ITEMS + e) * 16, 0, AUX_SC1));
+                        else
+                            part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
                     }
                 }
 #pragma unroll
@@ -446,6 +459,12 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                                 bv = y[r];
                                 bi = (float)(n + r);
                             }
+                        // the reference's scan starts from logits[0], and nothing displaces a NaN there
+                        // (sampler.c:86-97): +inf at index 0 wins every comparison downstream
+                        if (n == 0 && y[0] != y[0]) {
+                            bv = INFINITY;
+                            bi = 0.f;
+                        }
                     }
                     // (the partial tiles in `red` have been consumed: two barriers back)
                     float2* am = reinterpret_cast<float2*>(&red[0][0][0][0]);

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _first_max(rows):
-    """sampler.c:86-97: strict '>' scan from index 0."""
-    return np.array([int(np.flatnonzero(r == r.max())[0]) for r in rows], np.int32)
+    """sampler.c:86-97: strict '>' scan from index 0 (a NaN elsewhere never wins, a NaN at 0 is never displaced)."""
+    return np.array([0 if np.isnan(r[0]) else int(np.flatnonzero(r == np.nanmax(r))[0]) for r in rows], np.int32)
 
 
 def _device_argmax(hip, rows, slices):
@@ -41,6 +41,8 @@ def _tie_rows(V, r):
     rows[9, [V - 3, 7]] = np.float32(np.finfo(np.float32).max)
     rows[10, :] = np.float32(-0.0)
     rows[10, 11] = np.float32(0.0)                  # +0 == -0: still the first index
+    rows[11, 0] = np.nan                            # the scan starts from a NaN and never leaves it: index 0
+    rows[11, 7] = top
     return rows
 
 
