@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 matrix peak
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # per-kernel HBM bytes per launch from rocprofv3 --pmc passes (tools/gpu_evidence.sh)
 
 
 # --------------------------------------------------------------------------- helpers
