@@ -25,7 +25,8 @@
 // there is no grid barrier: every 16-token block has an arrival counter per phase; a tile's
 // producer stores write-through (sc1), drains, and adds one to the counters of the token blocks it
 // covers; a consumer polls the counters of the token blocks it reads (one lane, relaxed sc1 loads),
-// then loads past its vector cache (sc1).  All waits are bounded: a workgroup that waits longer
+// then loads past its vector cache (sc1; the attention phase, whose inputs include 2-byte stores, also
+// invalidates that cache first).  All waits are bounded: a workgroup that waits longer
 // than a fifth of a second marks the step faulty, stops waiting and finishes, so the launch always
 // ends.  Static tile assignment needs every workgroup resident at once, which a census at the
 // start checks before anything is written; if it fails (another process holds CUs) no workgroup
@@ -341,6 +342,15 @@ __global__ __launch_bounds__(CH_NW * 64) void k_decode_chain(ChainArgs) {
                 aw.clear_ring();
             }
             chain_wait(k, chain_counter(k, l, PH_QKV), PH_QKV, ma, s_word);
+            // The V rows of this step reach the pages as 2-byte write-through stores and q is read in
+            // 8-byte pieces: sizes for which loads past the vector cache alone are not known to suffice.
+            // So this phase also invalidates the CU's vector cache (agent acquire) before it reads them --
+            // issued by a wave that has no page loads in flight (the fence drains its issuer's loads).
+            if (threadIdx.x == 4 * 64) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate has completed
+            }
+            __syncthreads();
 #ifdef NVLLM_STAMPS
             unsigned long long* const st = k->stamps ? k->stamps + ((size_t)(l * CH_PHASES + PH_ATT) * gridDim.x + b) * 8 : nullptr;
             if (st && threadIdx.x == 0) st[0] = chain_clock();
