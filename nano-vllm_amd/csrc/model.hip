@@ -113,6 +113,17 @@ struct PassSlot {
     PassView view;
 };
 static PassSlot g_pass[PASS_RING];
+// Logits rows to the host (8 MB per 64-row pass at a 32,000-word vocabulary): the copies of a pass run on a
+// stream of their own, behind an event that follows the pass's kernels, so that the next pass's layers do
+// not queue behind 0.16 ms of PCIe traffic.  What the copies read (the logits and index workspaces) is
+// overwritten by the next pass's classifier, which therefore waits for `g_rows_copied` first.
+static hipEvent_t g_kernels_done = nullptr;
+static hipEvent_t g_rows_copied = nullptr;   // the event of the latest such copy that nobody has waited for yet
+static void wait_for_row_copies() {
+    if (!g_rows_copied) return;
+    HIP_CHECK(hipStreamWaitEvent(rt().stream, g_rows_copied, 0));
+    g_rows_copied = nullptr;
+}
 static long g_next_ticket = 0;
 static PassView g_seen;                // the most recently collected pass
 
@@ -147,12 +158,20 @@ static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int 
     }
     if (!slot.ev) HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
     hipStream_t stream = rt().stream;
+    if (rt().logits_mode == NVLLM_LOGITS_HOST) {
+        if (!rt().copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&rt().copy_stream, hipStreamNonBlocking));
+        if (!g_kernels_done) HIP_CHECK(hipEventCreateWithFlags(&g_kernels_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(g_kernels_done, stream));
+        stream = rt().copy_stream;
+        HIP_CHECK(hipStreamWaitEvent(stream, g_kernels_done, 0));
+    }
     // (with the status word of a one-launch step, which sits right behind the indices)
     HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)(B + (chained ? 1 : 0)) * sizeof(int), hipMemcpyDeviceToHost, stream));
     slot.chained = chained;
     if (rt().logits_mode == NVLLM_LOGITS_HOST)
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipEventRecord(slot.ev, stream));
+    if (rt().logits_mode == NVLLM_LOGITS_HOST) g_rows_copied = slot.ev;
     slot.ticket = ticket;
     view.argmax = slot.host;
     view.outputs = B;
@@ -643,6 +662,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     int* d_argmax = (int*)ws_get(WS_ARGMAX, (size_t)(p->max_seq_len + 64) * sizeof(int));
     if (m->f32) {   // fp32 weights: the reference's operator sequence
         if (st.d_tok_src) launch_patch_tokens(st.d_tokens, st.d_tok_src, d_argmax, T);
+        wait_for_row_copies();
         forward_f32(st, T, B, p, s, w, pool, rope, d_logits);
         launch_argmax(d_argmax, d_logits, B, V);
         return finish_pass(s, d_logits, d_argmax, B, V, PassView{});
@@ -655,6 +675,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     unsigned* chain_status = (unsigned*)(d_argmax + B);
     size_t sync_words = 0;
     if (try_chain) {
+        wait_for_row_copies();   // (the embedding kernel clears the status word, which sits behind the indices being copied)
         sync_words = chain_sync_words(p->n_layers);
         chain_sync = (unsigned*)ws_get(WS_CHAIN_SYNC, sync_words * sizeof(unsigned));
     }
@@ -749,6 +770,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         }
     }
     // logits only for the rows named by output_indices                            (model.c:396,411-418)
+    wait_for_row_copies();   // the previous pass's rows have left the workspaces the classifier writes
     bool identity = B == T;
     for (int k = 0; identity && k < B; k++) identity = output_indices[k] == k;
     const __half* a16_head = a16_x;
@@ -1021,11 +1043,26 @@ int sample(Sampler* s, float* logits) {
         // index that attains the maximum.  Two passes the compiler can vectorise: the maximum (a
         // NaN never wins a '>' and an initial NaN is never displaced, as in the reference), then
         // its first occurrence.
-        float top = logits[0];
-        for (int i = 1; i < V; i++) top = logits[i] > top ? logits[i] : top;
-        for (int i = 0; i < V; i++)
+        if (logits[0] != logits[0]) return 0;   // logits[0] is NaN: the reference's scan never leaves index 0
+        // (sixteen independent running maxima, each started from logits[0]: the host has 64 rows of
+        // 32,000 floats to scan per step, and one dependent compare per element is what bounds it)
+        float acc[16];
+        for (int j = 0; j < 16; j++) acc[j] = logits[0];
+        int i = 1;
+        for (; i + 16 <= V; i += 16)
+            for (int j = 0; j < 16; j++) acc[j] = logits[i + j] > acc[j] ? logits[i + j] : acc[j];
+        float top = acc[0];
+        for (int j = 1; j < 16; j++) top = acc[j] > top ? acc[j] : top;
+        for (; i < V; i++) top = logits[i] > top ? logits[i] : top;
+        // its first occurrence: whole chunks are tested without a branch per element
+        for (i = 0; i + 64 <= V; i += 64) {
+            int hit = 0;
+            for (int j = 0; j < 64; j++) hit |= (logits[i + j] == top);
+            if (hit) break;
+        }
+        for (; i < V; i++)
             if (logits[i] == top) return i;
-        return 0;   // logits[0] is NaN: the reference's scan never leaves index 0
+        return 0;
     }
     // temperature > 0: softmax and the nucleus filter run on the GPU, for all rows of the pass at once
     Prepared& pp = g_prep_pass;

@@ -78,6 +78,7 @@ struct Runtime {
     bool inited = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // result copies of a pass when logits rows travel to the host (created on first use)
     int logits_mode = NVLLM_LOGITS_HOST;
     int kv_elem_bytes = 4;
     bool kv_elem_set = false;   // nvllm_set_kv_elem_bytes was called: the environment default does not apply
@@ -85,6 +86,7 @@ struct Runtime {
 };
 Runtime& rt();
 void ensure_init();
+void sync_streams();   // the library stream and, if it exists, the copy stream
 // noalloc.hip: resolves the device address of the library's static scratch array for the current
 // device (called once by ensure_init, after hipSetDevice)
 void noalloc_setup(int device);

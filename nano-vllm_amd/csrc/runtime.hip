@@ -21,12 +21,17 @@ struct WsBuf {
 };
 static WsBuf g_ws[WS_COUNT];
 
+void sync_streams() {
+    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+    if (g_rt.copy_stream) HIP_CHECK(hipStreamSynchronize(g_rt.copy_stream));
+}
+
 void* ws_get(WsSlot slot, size_t bytes) {
     ensure_init();
     WsBuf& b = g_ws[slot];
     if (bytes > b.bytes) {
         if (b.p) {
-            HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+            sync_streams();
             HIP_CHECK(hipFree(b.p));
         }
         size_t want = bytes + bytes / 4;  // head-room: shapes creep up during prefill
@@ -293,7 +298,7 @@ int device_malloc(void** ptr, size_t size) {
 void device_free(void* ptr) {
     if (!ptr) return;
     ensure_init();
-    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+    sync_streams();
     auto& pl = pinned_list();
     for (size_t i = 0; i < pl.size(); i++)
         if (pl[i] == ptr) {
@@ -329,7 +334,7 @@ int device_memcpy(void* dst, const void* src, size_t size, DeviceMemcpyKind kind
 
 void device_sync(void) {
     ensure_init();
-    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+    sync_streams();
 }
 
 // ---- include/ops.h life-cycle ---------------------------------------------------
@@ -337,7 +342,7 @@ void init_ops(void) { ensure_init(); }
 
 void free_ops(void) {
     if (!g_rt.inited) return;
-    HIP_CHECK(hipStreamSynchronize(g_rt.stream));
+    sync_streams();
     prof_drain();
     for (int i = 0; i < WS_COUNT; i++) {
         if (g_ws[i].p) HIP_CHECK(hipFree(g_ws[i].p));
