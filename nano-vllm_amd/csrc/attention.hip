@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
 // SOLO: every wave takes an item of its own and walks all of its pages -- for short contexts with many
 // items (a 7B-shape decode batch: 4,096 items of 11 pages), where four waves sharing an item would
 // spend their time in the start-up and the merge rather than in the page loop.
-template <int HD, int PF, bool SOLO = false>
+template <int HD, int PF, bool SOLO = false, bool ONCE = false>
 __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     constexpr int STRIDE = SOLO ? 1 : 4;   // pages between two consecutive pages of one wave
     const int lane = threadIdx.x & 63;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_paged_attn16(AttnKArgs a) {
     // round-robin and merge through LDS at the end
     const unsigned widx = SOLO ? blockIdx.x * 4u + (unsigned)wave : blockIdx.x;
     if (SOLO && widx >= (unsigned)a.NG * (unsigned)a.nsplit * (unsigned)a.n_runs) return;   // (no barrier in this form)
-    Attn16Wave<HD, PF, STRIDE, false> w;
+    Attn16Wave<HD, PF, STRIDE, false, ONCE> w;
     w.setup(a, widx, SOLO ? 0 : wave, lane, 0);
     w.load_q();
     w.start();
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 
 // ------------------------------------------------------------------ launch
 template <int HD>
-static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo) {
+static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo, bool once) {
     const dim3 block(256);
     if (elem_bytes == 4) {   // fp32 rows: `units` are waves, four independent items per workgroup
         NVLLM_LAUNCH((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
@@ -367,7 +367,8 @@ static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo)
     // a wave per item
     if (solo) {
         // (two pages in flight per wave; four measured slower: 76.8 against 73.9 us at the 7B shape)
-        NVLLM_LAUNCH((k_paged_attn16<HD, 2, true>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
+        if (once) NVLLM_LAUNCH((k_paged_attn16<HD, 2, true, true>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
+        else NVLLM_LAUNCH((k_paged_attn16<HD, 2, true>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
         return;
     }
     const dim3 grid((unsigned)units);
@@ -376,6 +377,8 @@ static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo)
     static const int pf = getenv("NVLLM_ATTN_PF") ? atoi(getenv("NVLLM_ATTN_PF")) : 2;
     if (HD <= 64 && pf == 8)
         NVLLM_LAUNCH((k_paged_attn16<HD, (HD <= 64 ? 8 : 2)>), grid, block, 0, k);
+    else if ((pf == 2 || HD > 64) && once)
+        NVLLM_LAUNCH((k_paged_attn16<HD, 2, false, true>), grid, block, 0, k);
     else if (pf == 2 || HD > 64)
         NVLLM_LAUNCH((k_paged_attn16<HD, 2>), grid, block, 0, k);
     else
@@ -446,6 +449,8 @@ void launch_paged_attention(const AttnArgs& a) {
     k.Kb_out = cdiv(a.H * a.hd, 32);
     k.part_acc = nullptr;
     k.part_ml = nullptr;
+    static const int nt_env = getenv("NVLLM_ATTN_NT") ? atoi(getenv("NVLLM_ATTN_NT")) : 1;
+    const bool once = nt_env && a.n_runs == a.T;   // one token per run: no page is read by two items of a kv head
     if (nsplit > 1) {
         const size_t rows = (size_t)a.T * a.H * nsplit;
         float* part = (float*)ws_get(WS_ATT_PART, rows * (a.hd + 2) * sizeof(float));
@@ -457,13 +462,13 @@ void launch_paged_attention(const AttnArgs& a) {
         const double kvb = (double)a.kv_positions * 2.0 * a.KVH * a.hd * a.pool.elem_bytes;
         ProfScope ps(PC_ATTN, kvb + (double)a.T * a.H * a.hd * 8.0, 4.0 * (double)a.kv_positions * CT * a.H * a.hd);
         switch (a.hd) {
-            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes, solo); break;
-            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes, solo); break;
-            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes, solo); break;
-            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes, solo); break;
-            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes, solo); break;
-            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes, solo); break;
-            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes, solo); break;
+            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes, solo, once); break;
             default: NVLLM_FATAL("head_dim %d is not supported (16, 32, 48, 64, 80, 96, 128)", a.hd);
         }
     }

@@ -50,7 +50,7 @@ constexpr int attn16_lds() {
 
 // The state of one wave working on an item.  STRIDE = pages between two consecutive pages of the
 // wave (4: four waves share the item; 1: the wave owns it).
-template <int HD, int PF, int STRIDE, bool COH>
+template <int HD, int PF, int STRIDE, bool COH, bool ONCE = false>
 struct Attn16Wave {
     static constexpr int NC = HD / 16;
     AttnKArgs a;   // (a copy: a pointer to the caller's record would keep that record in memory)
@@ -137,10 +137,13 @@ struct Attn16Wave {
 #pragma unroll
             for (int c = 0; c < NC; c++) vr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rv, voff + 512 * c, 0, 16);
         } else {
+            // ONCE: a decode batch reads every page once -> non-temporal (aux 2 = nt); the items of a prompt
+            // chunk read the same pages and meet in L2 -> default policy
+            constexpr int POLICY = ONCE ? 2 : 0;
 #pragma unroll
-            for (int c = 0; c < NC; c++) kr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rk, voff + 512 * c, 0, 0);
+            for (int c = 0; c < NC; c++) kr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rk, voff + 512 * c, 0, POLICY);
 #pragma unroll
-            for (int c = 0; c < NC; c++) vr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rv, voff + 512 * c, 0, 0);
+            for (int c = 0; c < NC; c++) vr[slot][c] = __builtin_amdgcn_raw_buffer_load_b64(rv, voff + 512 * c, 0, POLICY);
         }
     }
 
