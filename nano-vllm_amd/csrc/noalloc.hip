@@ -81,9 +81,12 @@ extern "C" int nvllm_matmul_noalloc(float* out, const float* in, const float* we
     unsigned* counters = (unsigned*)base;
     __half* a16 = (__half*)(base + NOALLOC_COUNTER_BYTES);
     float* slab = (float*)(base + NOALLOC_COUNTER_BYTES + NOALLOC_A16_BYTES);
-    // the array keeps the previous call's contents; the arrival counters must start at zero
-    // (launches leave them zero, but a call that died half-way would not have)
-    HIP_CHECK(hipMemsetAsync(counters, 0, NOALLOC_COUNTER_BYTES, rt().stream));
+    // the array keeps the previous call's contents; the arrival counters this launch uses (one per output
+    // tile) must start at zero (launches leave them zero, but a call that died half-way would not have)
+    const GemmPlan pl = gemm_plan(out_dim, in_dim, num_tokens, GemmEpilogue::F32, 0, NOALLOC_COUNTERS, NOALLOC_SLAB_BYTES);
+    size_t zero_bytes = ((size_t)pl.tiles_n * pl.tiles_t * sizeof(unsigned) + 255) & ~(size_t)255;
+    if (zero_bytes > NOALLOC_COUNTER_BYTES) zero_bytes = NOALLOC_COUNTER_BYTES;
+    HIP_CHECK(hipMemsetAsync(counters, 0, zero_bytes, rt().stream));
     launch_pack_a16(a16, in, num_tokens, in_dim);
     GemmEpilogue e;
     e.kind = GemmEpilogue::F32;

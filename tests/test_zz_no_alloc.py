@@ -92,3 +92,43 @@ def test_matmul_noalloc_keeps_the_k_split_of_a_wide_projection(hip, tmp_models):
             np.testing.assert_array_equal(got, want)
     finally:
         hip.nvllm_free_model(C.byref(w))
+
+
+def test_matmul_noalloc_is_capturable_into_a_hip_graph(hip, tmp_models):
+    """One of the callers the entry point exists for: under stream capture an allocation is an error.  The
+    call is captured on the library's stream, instantiated and replayed; the replay's result is matmul()'s."""
+    path, shape = tmp_models("tiny", seed=71, dim=256, hidden_dim=4096, n_layers=1, n_heads=4, n_kv_heads=2,
+                             vocab_size=777, max_seq_len=128)
+    w, cfg = capi.Weights(), capi.Config()
+    hip.load_model(C.byref(w), C.byref(cfg), path.encode())
+    rtl = C.CDLL("libamdhip64.so")
+    try:
+        T, K, N = 64, cfg.hidden_dim, cfg.dim
+        handle = w.layers[0].w_down
+        x = np.random.Generator(np.random.PCG64(75)).standard_normal((T, K)).astype(np.float32)
+        dx = hip.to_device(x)
+        d_ref, d_new = hip.empty_device(T * N * 4), hip.empty_device(T * N * 4)
+        hip.matmul(d_ref, dx, handle, T, K, N)
+        assert hip.nvllm_matmul_noalloc(d_new, dx, handle, T, K, N) == 0      # first use outside the capture
+        hip.device_sync()
+        blank = np.full((T, N), np.nan, np.float32)
+        hip.device_memcpy(d_new, blank.ctypes.data, blank.nbytes, capi.HOST_TO_DEVICE)
+        stream = C.c_void_p(hip.nvllm_stream())
+        graph, executable = C.c_void_p(), C.c_void_p()
+        assert rtl.hipStreamBeginCapture(stream, 0) == 0
+        rc = hip.nvllm_matmul_noalloc(d_new, dx, handle, T, K, N)
+        assert rtl.hipStreamEndCapture(stream, C.byref(graph)) == 0 and rc == 0 and graph.value
+        hip.device_sync()
+        assert np.isnan(hip.to_host(d_new, (T, N))).all()                     # captured, not run
+        assert rtl.hipGraphInstantiate(C.byref(executable), graph, None, None, 0) == 0
+        for _ in range(2):
+            hip.device_memcpy(d_new, blank.ctypes.data, blank.nbytes, capi.HOST_TO_DEVICE)
+            assert rtl.hipGraphLaunch(executable, stream) == 0
+            hip.device_sync()
+            np.testing.assert_array_equal(hip.to_host(d_new, (T, N)), hip.to_host(d_ref, (T, N)))
+        rtl.hipGraphExecDestroy(executable)
+        rtl.hipGraphDestroy(graph)
+        for p in (dx, d_ref, d_new):
+            hip.free(p)
+    finally:
+        hip.nvllm_free_model(C.byref(w))
