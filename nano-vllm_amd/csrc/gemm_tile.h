@@ -189,7 +189,11 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
             lo = __builtin_bit_cast(h8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[j] + 1024, kb * 2048, AUX_SC1));
         } else {
             hi = ap[j][(size_t)kb * 128];
+#ifdef NVLLM_ABLATE_LO   // diagnostic builds only: what the second activation plane costs (results are then fp16-activation results)
+            lo = hi;
+#else
             lo = ap[j][(size_t)kb * 128 + 64];
+#endif
         }
     };
 
@@ -250,7 +254,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
 #pragma unroll
                     for (int j = 0; j < TB; j++) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], ah[r % RA][j], acc[i][j], 0, 0, 0);
+#ifndef NVLLM_ABLATE_LO
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][i], al[r % RA][j], acc[i][j], 0, 0, 0);
+#endif
                     }
                 if (s == 0) NVLLM_TSTAMP(2, acc[NBW - 1][TB - 1][0]);
                 if (s + RW < nsteps) {
