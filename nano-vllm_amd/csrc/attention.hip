@@ -126,16 +126,14 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
 
     const int rs = (int)a.rowstride;
     // page -> operand base pointers (wave-uniform: scalar loads of the block table)
-    auto kbase = [&](int pg) -> const KVT* {
+    // (a block of 16 * 2^bs_shift positions holds 2^bs_shift consecutive pages: memory.c:74-82)
+    const int sh = a.bs_shift;
+    auto row_of = [&](int pg) -> long {
         const int q = min(pg, pg_end - 1);
-        const long row = table ? (long)table[q] * 16 : (long)q * 16;
-        return pk + row * rs;
+        return table ? (((long)table[q >> sh]) << (4 + sh)) + ((long)(q & ((1 << sh) - 1)) << 4) : (long)q * 16;
     };
-    auto vbase = [&](int pg) -> const KVT* {
-        const int q = min(pg, pg_end - 1);
-        const long row = table ? (long)table[q] * 16 : (long)q * 16;
-        return pv + row * rs;
-    };
+    auto kbase = [&](int pg) -> const KVT* { return pk + row_of(pg) * rs; };
+    auto vbase = [&](int pg) -> const KVT* { return pv + row_of(pg) * rs; };
     auto live_of = [&](int pg) -> int { return min(16, plast - min(pg, pg_end - 1) * 16 + 1); };
 
     auto compute = [&](const PageRegs<HD, KVT>& r, int pg) {
@@ -400,8 +398,11 @@ void launch_paged_attention(const AttnArgs& a) {
     const int NG = a.H / GT;
     // The kernel walks pages of 16 positions; a pool with another block size is
     // addressed position by position through a page size of 1 ... not supported.
-    if (a.tables && a.pool.block_size != 16)
-        NVLLM_FATAL("paged attention supports block_size 16 (the driver's value), got %d", a.pool.block_size);
+    // pages of 16 positions: a block of fp32 rows may hold 1, 2, 4 ... of them; fp16 pages are blocks of 16
+    int bs_shift = 0;
+    while ((16 << bs_shift) < a.pool.block_size) bs_shift++;
+    if (a.tables && ((16 << bs_shift) != a.pool.block_size || (a.pool.elem_bytes == 2 && bs_shift != 0)))
+        NVLLM_FATAL("paged attention supports block sizes 16, 32, 64 ... for fp32 rows and 16 for fp16 pages, got %d", a.pool.block_size);
     if (a.pool.elem_bytes == 2 && !a.tables) NVLLM_FATAL("an fp16 KV pool is always paged");
     const long base_items = (long)a.n_runs * NG;
     const int pages = (a.max_pos + 16) / 16;
@@ -449,6 +450,7 @@ void launch_paged_attention(const AttnArgs& a) {
     k.Kb_out = cdiv(a.H * a.hd, 32);
     k.part_acc = nullptr;
     k.part_ml = nullptr;
+    k.bs_shift = bs_shift;
     static const int nt_env = getenv("NVLLM_ATTN_NT") ? atoi(getenv("NVLLM_ATTN_NT")) : 1;
     const bool once = nt_env && a.n_runs == a.T;   // one token per run: no page is read by two items of a kv head
     if (nsplit > 1) {

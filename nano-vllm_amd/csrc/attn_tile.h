@@ -38,6 +38,7 @@ struct AttnKArgs {
     int Kb_out;
     float* part_acc;  // [t][h][split][HD]
     float* part_ml;   // [t][h][split][2]
+    int bs_shift;     // fp32 rows: log2(block_size / 16) -- a block holds 2^bs_shift pages of 16 positions
 };
 
 __device__ __forceinline__ ah4_t as_ah4(au2_t v) { return __builtin_bit_cast(ah4_t, v); }

@@ -588,6 +588,7 @@ bool launch_decode_chain(const ChainStep& s) {
     k.Kb_out = cdiv(QD, 32);
     k.part_acc = nullptr;
     k.part_ml = nullptr;
+    k.bs_shift = 0;
     c.fresh_rule = s.one_token_per_seq ? 1 : 0;
     c.n_items = (int)items;
     // split-K partial tiles of the down projection

@@ -261,6 +261,17 @@ def test_prefill_batches_of_hundreds_of_tokens(hip, oracle, tmp_models, kv_bytes
     assert worst < (TIGHT_TOL if kv_bytes == 4 else LOGITS_TOL / 10), worst
 
 
+def test_forward_pass_with_blocks_of_32_positions(hip, oracle, tmp_models):
+    """The driver with block_size 32 (fp32 pool rows): allocation trace, tokens and logits as the oracle's."""
+    path, shape = tmp_models("tiny")
+    prompts = synth.make_requests(4, 5, 70, shape.vocab_size, seed=41)
+    kw = dict(n_new=20, arrivals=[0, 0, 1, 3], collect_logits=True, chunk_size=16, block_size=32, temperature=0.0, max_steps=300)
+    o = util.run_engine(oracle, path, prompts, **kw)
+    g = util.run_engine(hip, path, prompts, **kw)
+    worst = _compare_runs(g, o)
+    assert worst < TIGHT_TOL, worst
+
+
 def test_unmodified_reference_driver_runs_on_the_gpu(tmp_path):
     """The reference's own main() -- its scheduler loop, tokenizer, sampler, dashboards, compiled
     unmodified (oracle/_ref/nano_vllm_hip, built where /root/reference exists) and linked with

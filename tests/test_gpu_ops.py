@@ -332,6 +332,47 @@ def test_attention_at_the_benchmark_shape(hip, oracle, kv_bytes, lo, hi):
         po.close()
 
 
+@pytest.mark.parametrize("bs", [32, 64])
+def test_paged_attention_with_larger_blocks_of_fp32_rows(hip, oracle, bs):
+    """The reference's pool takes any block size (memory.c:74-82); the library's fp32 rows take 16, 32, 64 ...:
+    a block then holds several of the kernel's 16-position pages.  Scattered tables, contexts that end inside
+    a block, at a page boundary inside a block and at a block boundary."""
+    hd, H, KVH = 64, 8, 2
+    r = rng(bs)
+    L, S = 2, 1024
+    ctx = [1, 15, 16, 17, bs - 1, bs, bs + 1, 2 * bs + 5, 300, 1000]
+    n_seqs, maxb = len(ctx), S // bs
+    nb = sum((c + bs - 1) // bs for c in ctx) + 3
+    ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+    perm = r.permutation(nb)
+    cur = 0
+    for s, c in enumerate(ctx):
+        need = (c + bs - 1) // bs
+        blocks = perm[cur:cur + need].tolist()
+        cur += need
+        ph.set_table(s, blocks)
+        po.set_table(s, blocks)
+    kfill = r.standard_normal(ph.elems()).astype(np.float32)
+    vfill = r.standard_normal(ph.elems()).astype(np.float32)
+    ph.fill(kfill, vfill)
+    po.fill(kfill, vfill)
+    pos = [c - 1 for c in ctx]
+    sid = list(range(n_seqs))
+    T = len(pos)
+    k = r.standard_normal((T, KVH * hd)).astype(np.float32)
+    v = r.standard_normal((T, KVH * hd)).astype(np.float32)
+    q = r.standard_normal((T, H * hd)).astype(np.float32)
+    util.op_kv_write_batch(oracle, po, k, v, 1, pos, sid, KVH, hd)
+    util.op_kv_write_batch(hip, ph, k, v, 1, pos, sid, KVH, hd)
+    np.testing.assert_array_equal(ph.dump("k"), po.dump("k"))
+    np.testing.assert_array_equal(ph.dump("v"), po.dump("v"))
+    want = util.op_paged_attention_batch(oracle, po, q, 1, pos, sid, S, H, KVH, hd)
+    got = util.op_paged_attention_batch(hip, ph, q, 1, pos, sid, S, H, KVH, hd)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6 * np.abs(want).max() + 2e-6)
+    ph.close()
+    po.close()
+
+
 def test_kv_write_table_too_small_stops(hip, oracle, capfd):
     """Reference attention.c:159-162: the first token whose logical block is not in
     the table prints and ends the call; later tokens are not written."""
