@@ -14,7 +14,8 @@ block pool; there is no data-path collective, so scaling is "weak".
 
 With --tp the N processes hold ONE model instead (BASELINE.json configs[4]: Llama-2-7B
 shape, batch 128): heads and MLP columns are split over the ranks and the two partial
-sums per layer are all-reduced with RCCL on the library's stream; every rank runs the
+sums per layer are all-reduced on the library's stream (RCCL, or with --tp-exchange peer the
+library's own kernel over peer-mapped memory); every rank runs the
 same 128 requests, `value` counts them once and scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `value` is decode tokens/s over all ranks with the
@@ -133,6 +134,15 @@ class DistEnv:
         self.dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
 
+    def allgather_bytes(self, payload: bytes, n: int) -> bytes:
+        """Every rank's `n` bytes, concatenated in rank order, on every rank."""
+        if not self.dist:
+            return payload
+        mine = self.torch.frombuffer(bytearray(payload), dtype=self.torch.uint8).to(self.device)
+        parts = [self.torch.zeros(n, dtype=self.torch.uint8, device=self.device) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return b"".join(bytes(t.cpu().numpy().tobytes()) for t in parts)
+
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
@@ -194,6 +204,16 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
         run_gpu._noop = capi.ALLREDUCE_FN(lambda ctx, buf, count, stream: None)
         if lib.nvllm_tp_init_custom(rank, world, run_gpu._noop, None) != 0:
             raise SystemExit("bench: tensor-parallel slice setup failed")
+    elif args.tp and args.tp_exchange == "peer" and not getattr(run_gpu, "_tp_up", False):
+        run_gpu._tp_up = True
+        # the library's own all-reduce: every rank exports one exchange segment (hipIpc handle) and maps the
+        # others'; its kernels store into the peers' HBM over xGMI (no RCCL)
+        buf = (C.c_ubyte * capi.TP_PEER_HANDLE_BYTES)()
+        if lib.nvllm_tp_peer_handle(buf) != 0:
+            raise SystemExit("bench: the peer exchange segment could not be exported")
+        handles = env.allgather_bytes(bytes(buf), capi.TP_PEER_HANDLE_BYTES)
+        if lib.nvllm_tp_init_peer(env.rank, env.world, handles) != 0:
+            raise SystemExit("bench: tensor-parallel setup (peer exchange) failed")
     elif args.tp and not getattr(run_gpu, "_tp_up", False):
         run_gpu._tp_up = True
         # one RCCL communicator over all ranks, owned by the library: its all-reduces run on the
@@ -252,8 +272,9 @@ def run_gpu(args, env, shape, model_path, kv_bytes=None, logits_host=None, steps
 
     # ---- per-kernel durations from HIP events on the library stream (same workload,
     #      the steps right after the timed region; events would perturb the timing)
+    #      Under --tp every rank takes these steps (a rank cannot all-reduce alone); rank 0's events are reported.
     prof = {}
-    if env.rank == 0 and args.profile_steps > 0:
+    if (env.rank == 0 or args.tp) and args.profile_steps > 0:
         lib.nvllm_prof_reset()
         lib.nvllm_prof_enable(1)
         for _ in range(args.profile_steps):
@@ -324,6 +345,8 @@ def main():
     ap.add_argument("--tp", action="store_true",
                     help="the ranks hold ONE model, split by heads / MLP columns, with RCCL all-reduces (default workload: "
                          "llama2-7b shape, batch 128, 128-token prompts)")
+    ap.add_argument("--tp-exchange", choices=("rccl", "peer"), default=os.environ.get("NVLLM_TP_EXCHANGE", "rccl"),
+                    help="with --tp: ncclAllReduce (default), or the library's all-reduce over peer-mapped exchange segments")
     ap.add_argument("--tp-slice", default=None, metavar="R/W",
                     help="with --tp on ONE GPU: time rank R's share of a model split over W ranks with a no-op exchange "
                          "(what a rank of a W-GPU run computes between its all-reduces; results are meaningless)")
@@ -432,7 +455,7 @@ def main():
                                    f"{args.prompt_len}-token prompts prefilled in {args.chunk}-token chunks, greedy decode, "
                                    f"paged KV (block 16, {'fp32' if args.kv_bytes == 4 else 'fp16'} pool), "
                                    f"mean context {r['ctx']} in the timed region",
-                       "batch_per_gpu": B, "parallelism": f"one rank of tp{args.tp_slice[1]}, no exchange" if args.tp_slice else f"tp{N}" if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes,
+                       "batch_per_gpu": B, "parallelism": f"one rank of tp{args.tp_slice[1]}, no exchange" if args.tp_slice else (f"tp{N} ({args.tp_exchange} exchange)" if N > 1 else f"tp{N}") if args.tp else (f"dp{N}" if N > 1 else "single"), "kv_elem_bytes": args.kv_bytes,
                        "result_handoff": "logits rows to host (PCIe-inclusive)" if args.logits_host else "token ids only"},
             "roofline": roofline,
             "roofline_by_kernel": by_kernel,

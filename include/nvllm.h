@@ -151,6 +151,26 @@ int nvllm_tp_init(int rank, int world, const void* id);
 typedef void (*nvllm_allreduce_fn)(void* ctx, float* device_buf, size_t count, void* hip_stream);
 int nvllm_tp_init_custom(int rank, int world, nvllm_allreduce_fn fn, void* ctx);
 
+/* The same with the library's own exchange over peer-mapped memory (no RCCL): every rank owns one
+ * exchange segment in its HBM, exported by hipIpcGetMemHandle; a rank's all-reduce kernel stores its
+ * slices straight into the other ranks' segments over xGMI and reads their results back (one launch
+ * per all-reduce, two flag hops, count/world floats each way per link; every element is summed by
+ * one rank in rank order, so all ranks hold the same bits).  No counterpart in the reference, whose
+ * forward pass runs in one process (the sums it replaces: src/model.c:385,392).
+ *   every rank:  nvllm_tp_peer_handle(mine);            then all-gather the handles in rank order
+ *   every rank:  nvllm_tp_init_peer(rank, world, all);  (world <= 8)
+ * Every rank must make the same sequence of forward calls.  A rank that waits 30 s for a peer stops
+ * the process with a message at its next call.  Both return 0, or -1 with a message. */
+#define NVLLM_TP_PEER_HANDLE_BYTES 64
+int nvllm_tp_peer_handle(void* handle /* NVLLM_TP_PEER_HANDLE_BYTES */);
+int nvllm_tp_init_peer(int rank, int world, const void* handles /* world x NVLLM_TP_PEER_HANDLE_BYTES */);
+/* all-reduces made through the peer exchange since nvllm_tp_init_peer, and the floats they carried */
+void nvllm_tp_peer_stats(unsigned long long* calls, unsigned long long* floats);
+
+/* The session's all-reduce on a caller's device buffer (in place, sum over the ranks, enqueued on
+ * nvllm_stream()): for hosts that need the same exchange outside the forward pass.  -1 without a session. */
+int nvllm_tp_allreduce(float* device_buf, size_t count);
+
 void nvllm_tp_finalize(void);
 int  nvllm_tp_rank(void);
 int  nvllm_tp_world(void);

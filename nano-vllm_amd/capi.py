@@ -65,6 +65,7 @@ class TpShard(C.Structure):
 # void fn(void* ctx, float* device_buf, size_t count, void* hip_stream)
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 TP_ID_BYTES = 128
+TP_PEER_HANDLE_BYTES = 64
 
 
 class EngineOptions(C.Structure):
@@ -173,6 +174,10 @@ _HIP_ONLY = {
     "nvllm_tp_unique_id": (_I, [_P]),
     "nvllm_tp_init": (_I, [_I, _I, _P]),
     "nvllm_tp_init_custom": (_I, [_I, _I, ALLREDUCE_FN, _P]),
+    "nvllm_tp_peer_handle": (_I, [_P]),
+    "nvllm_tp_init_peer": (_I, [_I, _I, _P]),
+    "nvllm_tp_peer_stats": (_V, [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "nvllm_tp_allreduce": (_I, [_P, C.c_size_t]),
     "nvllm_tp_finalize": (_V, []),
     "nvllm_tp_rank": (_I, []),
     "nvllm_tp_world": (_I, []),

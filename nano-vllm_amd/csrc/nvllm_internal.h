@@ -103,6 +103,7 @@ TpState& tp();
 void tp_allreduce(float* buf, size_t count);   // in place, on the library stream
 // recv[r * count .. ) = rank r's `count` floats at send, on every rank (send must not overlap recv)
 void tp_allgather(const float* send, float* recv, size_t count);
+void tp_peer_finalize();   // tp_peer.hip: unmaps the other ranks' exchange segments (no-op without a peer session)
 
 // Grow-only device scratch, one buffer per slot.
 enum WsSlot {

@@ -187,6 +187,7 @@ void nvllm_tp_finalize(void) {
     TpState& s = tp();
     if (!s.active) return;
     HIP_CHECK(hipStreamSynchronize(rt().stream));
+    tp_peer_finalize();
     if (g_comm) {
         g_rccl.CommDestroy(g_comm);
         g_comm = nullptr;

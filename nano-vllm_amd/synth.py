@@ -28,6 +28,7 @@ SHAPES = {
     # name: dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, max_seq_len
     "tiny": (64, 160, 2, 4, 2, 512, 128),
     "tiny-mha48": (96, 224, 2, 2, 2, 384, 96),        # head_dim 48, like stories15M
+    "tiny-gqa": (256, 512, 3, 8, 4, 600, 160),        # grouped heads that divide over 2 or 4 tensor-parallel ranks
     "stories15M": (288, 768, 6, 6, 6, 32000, 256),
     "stories42M": (512, 1376, 8, 8, 8, 32000, 1024),
     "tinyllama-1.1b": (2048, 5632, 22, 32, 4, 32000, 2048),

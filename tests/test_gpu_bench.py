@@ -75,3 +75,22 @@ def test_two_data_parallel_ranks_rehearsed_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+
+
+def test_two_tensor_parallel_ranks_with_the_peer_exchange_on_one_gpu(tmp_path):
+    """`bench.py --tp --tp-exchange peer` under the launcher with two ranks: ONE model split over both, the two
+    partial sums per layer all-reduced by the library's own kernel through exchange segments the ranks map from
+    each other (hipIpc handles, gathered over gloo).  Both ranks share this box's GPU, so the throughput means
+    nothing; the line must be the strong-scaling one with every request counted once."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tp", "--tp-exchange", "peer",
+           "--model-dir", str(tmp_path), "--model", "tiny-gqa", "--batch", "8", "--prompt-len", "40", "--chunk", "32",
+           "--max-seq-len", "160", "--steps", "6", "--warmup", "2", "--profile-steps", "2", "--cpu-steps", "0"]
+    env = dict(os.environ, NVLLM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "tp2 (peer exchange)"
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3

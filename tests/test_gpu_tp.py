@@ -155,23 +155,27 @@ def test_setup_is_refused_twice_and_for_bad_placements(hip):
     assert (hip.nvllm_tp_rank(), hip.nvllm_tp_world()) == (0, 1)
 
 
-@pytest.mark.parametrize("world,kv_bytes,over", [
-    (2, 4, dict(hidden_dim=192)),          # "tiny": 4 heads / 2 kv heads of width 16
-    (2, 2, GQA),
-    (4, 4, GQA),                           # one kv head (two query heads) per rank
-    (2, 4, LLAMA7B_LAYER),                 # 16 heads of 128 and 5504 hidden columns per rank (fp32 rows: the sampled-token
+@pytest.mark.parametrize("world,kv_bytes,over,exchange", [
+    (2, 4, dict(hidden_dim=192), "host"),  # "tiny": 4 heads / 2 kv heads of width 16
+    (2, 2, GQA, "host"),
+    (4, 4, GQA, "host"),                   # one kv head (two query heads) per rank
+    (2, 4, LLAMA7B_LAYER, "host"),         # 16 heads of 128 and 5504 hidden columns per rank (fp32 rows: the sampled-token
                                            # comparison draws from probabilities that must agree to ~1e-6)
+    (2, 2, GQA, "peer"),                   # the library's own exchange: kernels that store into each other's segments
+    (4, 4, GQA, "peer"),
+    (2, 4, LLAMA7B_LAYER, "peer"),
 ])
-def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_bytes, over):
-    """`world` processes, each with its slice of the weights and of the KV pool, the
-    exchange staged through the host (gloo); every rank must reproduce the oracle's
-    tokens, allocation trace and logits."""
+def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_bytes, over, exchange):
+    """`world` processes, each with its slice of the weights and of the KV pool; the exchange
+    staged through the host (gloo), or the library's all-reduce over peer-mapped exchange
+    segments (hipIpc handles; here all segments lie in the one GPU's memory, on a node each in
+    its own GPU's).  Every rank must reproduce the oracle's tokens, allocation trace and logits."""
     path, shape = tmp_models("tiny", seed=5, **over)
     big = over.get("dim", 0) >= 4096
     spec = dict(name="tiny", over=over, model_path=path, n_seqs=3 if big else 5, seed=23, n_new=8 if big else 16, chunk=12,
-                kv_bytes=kv_bytes, out_dir=str(tmp_path))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else "2")
-    port = 29620 + world + kv_bytes + (40 if big else 0)
+                kv_bytes=kv_bytes, out_dir=str(tmp_path), exchange=exchange)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else "2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29620 + world + kv_bytes + (40 if big else 0) + (100 if exchange == "peer" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "tests", "tp_worker.py"), json.dumps(spec)],
@@ -187,3 +191,24 @@ def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_
         # exchange only sums, so a gather is a sum over zero-padded slices)
         assert r["allreduce_calls"] == (2 * r["n_layers"] + 1) * r["steps"]
         assert r["allreduce_floats"] == 2 * r["n_layers"] * r["dim"] * r["tokens_forwarded"] + world * r["vocab_slice"] * r["output_rows"]
+        if exchange == "peer":
+            print(f"peer all-reduce of 128 x 4096 floats, {world} ranks on one GPU: {r['allreduce_us_128x4096']:.1f} us (rank {rank})")
+
+
+def test_a_rank_left_alone_by_its_peers_stops_with_a_message(tmp_path, tmp_models):
+    """Rank 0 makes three all-reduce calls that rank 1 never makes.  The kernels' waits are bounded (2 s here, 30 s
+    by default) and only the first one is sat out; the launches end, and the next call stops the process with a message."""
+    path, shape = tmp_models("tiny", seed=5, **GQA)
+    spec = dict(name="tiny", over=GQA, model_path=path, n_seqs=1, seed=23, n_new=1, chunk=12, kv_bytes=2, out_dir=str(tmp_path),
+                exchange="peer", lonely_call=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", NVLLM_TP_PEER_WAIT_S="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29791",
+                          os.path.join(ROOT, "tests", "tp_worker.py"), json.dumps(spec)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    text = out.stdout + out.stderr
+    assert "LONELY waited" in text and "LONELY still alive" not in text, text[-3000:]
+    waited = float(text.split("LONELY waited")[1].split()[0])
+    assert 1.5 < waited < 8.0, waited          # one wait of 2 s (phase A), not one per call and phase
+    assert "waited 2 s for a flag" in text, text[-3000:]

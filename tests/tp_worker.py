@@ -1,10 +1,12 @@
 """One tensor-parallel rank for tests/test_gpu_tp.py (started by torch.distributed.run).
 
 Every rank loads its slice of the same model file into the HIP library, with the
-all-reduce supplied by this script: the partial sums go through the host and a gloo
-all_reduce, so that several ranks can share the one GPU of a test box (RCCL itself
-refuses two ranks on one device).  Every rank also runs the CPU oracle on the whole
-model and compares."""
+all-reduce either supplied by this script -- the partial sums go through the host and a
+gloo all_reduce -- or the library's own exchange over peer-mapped memory (spec "exchange":
+"peer"; the handles travel by gloo).  Both let several ranks share the one GPU of a test box
+(RCCL itself refuses two ranks on one device).  Every rank also runs the CPU oracle on the
+whole model and compares."""
+import time
 import ctypes as C
 import json
 import os
@@ -51,11 +53,68 @@ def main():
         calls["n"] += 1
         calls["floats"] += count
 
-    cb = capi.ALLREDUCE_FN(allreduce)
-    assert hip.nvllm_tp_init_custom(rank, world, cb, None) == 0
+    peer = spec.get("exchange") == "peer"
+    timing = None
+    if peer:
+        mine = (C.c_ubyte * capi.TP_PEER_HANDLE_BYTES)()
+        assert hip.nvllm_tp_peer_handle(mine) == 0
+        gathered = [torch.zeros(capi.TP_PEER_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(list(mine), dtype=torch.uint8))
+        handles = (C.c_ubyte * (capi.TP_PEER_HANDLE_BYTES * world))(*[int(b) for t in gathered for b in t])
+        assert hip.nvllm_tp_init_peer(rank, world, handles) == 0
+        if spec.get("lonely_call"):
+            # rank 0 all-reduces alone: its kernel must give up after NVLLM_TP_PEER_WAIT_S, the launch must end,
+            # and the next call on the host must stop the process with a message (the test reads stderr)
+            dev = C.c_void_p()
+            assert hip.device_malloc(C.byref(dev), 4096) == 0
+            if rank == 0:
+                t0 = time.perf_counter()
+                hip.nvllm_tp_allreduce(dev, 1024)
+                hip.nvllm_tp_allreduce(dev, 1024)      # behind a wait that ran out nothing waits again
+                hip.nvllm_tp_allreduce(dev, 1024)
+                hip.device_sync()
+                print(f"LONELY waited {time.perf_counter() - t0:.1f} s", flush=True)
+                hip.nvllm_tp_allreduce(dev, 1024)      # aborts here
+                print("LONELY still alive", flush=True)
+            return
+        # the exchange alone, on known values: rank r contributes (r + 1) * pattern
+        for n in spec.get("probe_counts", [4, 1000, 128 * 4096, (1 << 20) + 2052]):
+            pattern = ((np.arange(n) % 251) - 125).astype(np.float32) / 64
+            host = (pattern * (rank + 1)).astype(np.float32)
+            dev = C.c_void_p()
+            assert hip.device_malloc(C.byref(dev), host.nbytes) == 0
+            hip.device_memcpy(dev, host.ctypes.data, host.nbytes, capi.HOST_TO_DEVICE)
+            assert hip.nvllm_tp_allreduce(dev, n) == 0
+            hip.device_sync()
+            back = np.empty_like(host)
+            hip.device_memcpy(back.ctypes.data, dev, host.nbytes, capi.DEVICE_TO_HOST)
+            want_sum = np.zeros(n, np.float32)
+            for r in range(world):                      # the exchange's own order: rank 0 first
+                want_sum = want_sum + pattern * np.float32(r + 1)
+            assert np.array_equal(back, want_sum), (rank, n, int((back != want_sum).sum()))
+            if n == 128 * 4096:                         # BASELINE.json configs[4]'s message: 128 rows x 4096 fp32
+                dist.barrier()
+                reps = 200
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    hip.nvllm_tp_allreduce(dev, n)
+                hip.device_sync()
+                timing = (time.perf_counter() - t0) / reps * 1e6
+            hip.device_free(dev)
+        c0, f0 = C.c_ulonglong(), C.c_ulonglong()
+        hip.nvllm_tp_peer_stats(C.byref(c0), C.byref(f0))
+    else:
+        cb = capi.ALLREDUCE_FN(allreduce)
+        assert hip.nvllm_tp_init_custom(rank, world, cb, None) == 0
     assert (hip.nvllm_tp_rank(), hip.nvllm_tp_world()) == (rank, world)
+    dist.barrier()    # the ranks start the forward passes together (the oracle runs above took different times)
     got = util.run_engine(hip, path, prompts, **kw)
-    reduce_calls, reduce_floats = calls["n"], calls["floats"]
+    if peer:
+        c1, f1 = C.c_ulonglong(), C.c_ulonglong()
+        hip.nvllm_tp_peer_stats(C.byref(c1), C.byref(f1))
+        reduce_calls, reduce_floats = c1.value - c0.value, f1.value - f0.value
+    else:
+        reduce_calls, reduce_floats = calls["n"], calls["floats"]
     # arg-max hand-off: the ranks exchange one (max, index) pair per row instead of logits
     hip.nvllm_set_logits_mode(1)
     kw2 = dict(kw, collect_logits=False)
@@ -82,7 +141,7 @@ def main():
                same_argmax=bool(same_argmax), same_sampled=bool(same_sampled),
                allreduce_calls=reduce_calls, allreduce_floats=reduce_floats, steps=len(want["steps"]),
                tokens_forwarded=tokens_forwarded, n_layers=shape.n_layers, dim=shape.dim,
-               output_rows=rows, vocab_slice=sh.vocab_slice, vocab=[sh.vocab0, sh.vocab])
+               output_rows=rows, vocab_slice=sh.vocab_slice, vocab=[sh.vocab0, sh.vocab], allreduce_us_128x4096=timing)
     with open(os.path.join(spec["out_dir"], f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
     dist.barrier()
