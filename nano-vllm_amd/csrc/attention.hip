@@ -76,21 +76,24 @@ __device__ __forceinline__ void load_page(PageRegs<HD, KVT>& r, const KVT* __res
     }
 }
 
-template <int HD, typename KVT>
-__global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
+// NSW = 0: every wave is an (item, key slice) of its own, four per workgroup; slices leave partials in
+// memory for k_attn_combine.  NSW = 4 or 8: the NSW waves of a workgroup are the key slices of ONE item
+// (a.nsplit = NSW) and merge through LDS -- no partials in memory, no second launch.
+template <int HD, typename KVT, int NSW = 0>
+__global__ __launch_bounds__(NSW == 8 ? 512 : 256) void k_paged_attn(AttnKArgs a) {
     constexpr int NC = HD / 16, NV = (HD + 63) / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // 32-bit index arithmetic throughout (64-bit division is a long software loop)
     const unsigned NG = (unsigned)a.NG;
-    const unsigned widx = blockIdx.x * 4u + (unsigned)wave;
-    if (widx >= (unsigned)a.n_runs * NG * (unsigned)a.nsplit) return;
-    // head group fastest: the waves of a workgroup read neighbouring 256-byte
-    // pieces of the same K/V rows at the same time (DRAM page locality)
-    const int hg = (int)(widx % NG);
-    const unsigned rest = widx / NG;
-    const int split = (int)(rest % (unsigned)a.nsplit);
-    const int4 run = a.runs[rest / (unsigned)a.nsplit];
+    const unsigned widx = NSW ? blockIdx.x * (unsigned)NSW + (unsigned)wave : blockIdx.x * 4u + (unsigned)wave;
+    if (NSW == 0 && widx >= (unsigned)a.n_runs * NG * (unsigned)a.nsplit) return;
+    // NSW = 0: head group fastest -- the waves of a workgroup read neighbouring 256-byte
+    // pieces of the same K/V rows at the same time (DRAM page locality); NSW > 0: slice fastest
+    const int hg = NSW ? (int)((widx / (unsigned)NSW) % NG) : (int)(widx % NG);
+    const unsigned rest = NSW ? (widx / (unsigned)NSW) / NG : widx / NG;
+    const int split = NSW ? wave : (int)(rest % (unsigned)a.nsplit);
+    const int4 run = a.runs[NSW ? rest : rest / (unsigned)a.nsplit];
     const int t0 = run.x, ntok = run.y, plast = run.z;   // positions rise by one within a run
     const int h0 = hg * a.GT;
     const int kvh = (int)((unsigned)h0 / (unsigned)a.group);
@@ -202,6 +205,63 @@ __global__ __launch_bounds__(256) void k_paged_attn(AttnKArgs a) {
     // ---- results: lane (col x, g) holds dims 64n + 16g + 4r + e of its column
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
+    if constexpr (NSW > 0) {
+        // the slices of the item meet in LDS; wave w then finishes the units (n, r) with 4n + r = w (mod NSW):
+        // four consecutive dims of every column, summed over the slices in slice order as k_attn_combine does
+        __shared__ float s_m[NSW][16], s_l[NSW][16];
+        __shared__ f4_t s_o[NSW][NV * 4][64];
+        if (g == 0) {
+            s_m[wave][x] = m;
+            s_l[wave][x] = lsum;
+        }
+#pragma unroll
+        for (int n = 0; n < NV; n++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) s_o[wave][n * 4 + e][lane] = oacc[n][e];
+        __syncthreads();
+        if (!cvalid) return;
+        const int h = h0 + chead;
+        float M = -INFINITY;
+#pragma unroll
+        for (int sl = 0; sl < NSW; sl++) M = fmaxf(M, s_m[sl][x]);
+        float f[NSW], L = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSW; sl++) {
+            f[sl] = expf(s_m[sl][x] - M);   // empty slices carry max = -inf -> weight 0
+            L = fmaf(s_l[sl][x], f[sl], L);
+        }
+        const float inv = 1.0f / L;
+        for (int u = wave; u < NV * 4; u += NSW) {
+            const int n = u >> 2, rr = u & 3;
+            const int d0 = 64 * n + 16 * g + 4 * rr;
+            if (d0 >= HD) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NSW; sl++) acc = fmaf(s_o[sl][n * 4 + e][lane][rr], f[sl], acc);
+                o[e] = acc * inv;
+            }
+            if (a.out_f32)
+                *reinterpret_cast<float4*>(a.out_f32 + ((size_t)tcol * a.H + h) * HD + d0) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.out_a16) {
+                const int kk = h * HD + d0;
+                alignas(8) __half hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float xv = fminf(fmaxf(o[e], -65504.f), 65504.f);
+                    hi[e] = __float2half_rn(xv);
+                    lo[e] = __float2half_rn(xv - __half2float(hi[e]));
+                }
+                const size_t tl = ((size_t)(tcol >> 4) * a.Kb_out + (kk >> 5)) * 2;
+                const size_t off = (size_t)((tcol & 15) + 16 * ((kk >> 3) & 3)) * 8 + (kk & 7);
+                *reinterpret_cast<uint2*>(a.out_a16 + tl * TILE_HALVES + off) = *reinterpret_cast<const uint2*>(hi);
+                *reinterpret_cast<uint2*>(a.out_a16 + (tl + 1) * TILE_HALVES + off) = *reinterpret_cast<const uint2*>(lo);
+            }
+        }
+        return;
+    }
     if (!cvalid) return;
     const int h = h0 + chead;
     if (a.nsplit > 1) {
@@ -355,10 +415,15 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 
 // ------------------------------------------------------------------ launch
 template <int HD>
-static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo, bool once) {
+static void launch_hd(const AttnKArgs& k, long units, int elem_bytes, bool solo, bool once, int merge_waves) {
     const dim3 block(256);
-    if (elem_bytes == 4) {   // fp32 rows: `units` are waves, four independent items per workgroup
-        NVLLM_LAUNCH((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
+    if (elem_bytes == 4) {   // fp32 rows: `units` are waves
+        if (merge_waves == 8)        // the eight (four) key slices of an item in one workgroup
+            NVLLM_LAUNCH((k_paged_attn<HD, float, 8>), dim3((unsigned)(units / 8)), dim3(512), 0, k);
+        else if (merge_waves == 4)
+            NVLLM_LAUNCH((k_paged_attn<HD, float, 4>), dim3((unsigned)(units / 4)), block, 0, k);
+        else                         // four independent (item, slice) waves per workgroup
+            NVLLM_LAUNCH((k_paged_attn<HD, float>), dim3((unsigned)((units + 3) / 4)), block, 0, k);
         return;
     }
     // fp16 pages: `units` are items.  Four cooperating waves per item, or -- many items of few pages --
@@ -419,6 +484,14 @@ void launch_paged_attention(const AttnArgs& a) {
     const int min_pages = wg_items ? 8 : 2;   // pages per slice worth a slice
     if (nsplit > (pages + min_pages - 1) / min_pages) nsplit = (pages + min_pages - 1) / min_pages;
     if (nsplit < 1) nsplit = 1;
+    // fp32 rows, 2..8 slices per item: the slices of an item share a workgroup (4 or 8 waves) and merge in LDS
+    // instead of going through memory and k_attn_combine (NVLLM_ATTN_MERGE=0 keeps the two launches)
+    static const int env_merge = getenv("NVLLM_ATTN_MERGE") ? atoi(getenv("NVLLM_ATTN_MERGE")) : 1;
+    int merge_waves = 0;
+    if (!wg_items && env_merge && nsplit > 1 && nsplit <= 8) {
+        merge_waves = nsplit <= 4 ? 4 : 8;
+        nsplit = merge_waves;
+    }
     const long waves = base_items * nsplit;
     // a wave per item: at least eight items per CU and at most 16 pages each
     static const int env_solo = getenv("NVLLM_ATTN_SOLO") ? atoi(getenv("NVLLM_ATTN_SOLO")) : -1;
@@ -453,7 +526,7 @@ void launch_paged_attention(const AttnArgs& a) {
     k.bs_shift = bs_shift;
     static const int nt_env = getenv("NVLLM_ATTN_NT") ? atoi(getenv("NVLLM_ATTN_NT")) : 1;
     const bool once = nt_env && a.n_runs == a.T;   // one token per run: no page is read by two items of a kv head
-    if (nsplit > 1) {
+    if (nsplit > 1 && !merge_waves) {
         const size_t rows = (size_t)a.T * a.H * nsplit;
         float* part = (float*)ws_get(WS_ATT_PART, rows * (a.hd + 2) * sizeof(float));
         k.part_acc = part;
@@ -464,17 +537,17 @@ void launch_paged_attention(const AttnArgs& a) {
         const double kvb = (double)a.kv_positions * 2.0 * a.KVH * a.hd * a.pool.elem_bytes;
         ProfScope ps(PC_ATTN, kvb + (double)a.T * a.H * a.hd * 8.0, 4.0 * (double)a.kv_positions * CT * a.H * a.hd);
         switch (a.hd) {
-            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes, solo, once); break;
-            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes, solo, once); break;
+            case 16: launch_hd<16>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 32: launch_hd<32>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 48: launch_hd<48>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 64: launch_hd<64>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 80: launch_hd<80>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 96: launch_hd<96>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
+            case 128: launch_hd<128>(k, waves, a.pool.elem_bytes, solo, once, merge_waves); break;
             default: NVLLM_FATAL("head_dim %d is not supported (16, 32, 48, 64, 80, 96, 128)", a.hd);
         }
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && !merge_waves) {
         ProfScope ps(PC_ATTN_COMBINE, (double)a.T * a.H * nsplit * (a.hd + 2) * 4.0, 0);
         const long threads = (long)a.T * a.H * (a.hd / 8);
         NVLLM_LAUNCH(k_attn_combine, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
