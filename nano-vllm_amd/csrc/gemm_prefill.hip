@@ -606,6 +606,11 @@ void launch_gemm_prefill(GemmArgs a) {
     if (shape == 3 && !wide_decode) {
         if (tiles4 <= cus) {
             tw = 2;
+        } else if (tiles_n * cdiv(a.Tb, 4) <= 2 * cus) {
+            // a few more 128-token tiles than CUs: some CUs would run two tall tiles in a row (or side by side)
+            // while the rest run one; 64-token tiles give every CU at most two short ones (TinyLlama's
+            // q/k/v at 1,591 tokens: 340 tiles of 96 tokens -> 500 of 64, 52 -> 47 us)
+            tw = 2;
         } else {
             const int slots = 3 * cus;
             const int tiles3 = tiles_n * cdiv(a.Tb, 6);
@@ -613,6 +618,8 @@ void launch_gemm_prefill(GemmArgs a) {
         }
     }
     if (shape == 3 && tw_env >= 2 && tw_env <= 4) tw = tw_env;
+    static const int tw_qkv_env = getenv("NVLLM_GEMM_PREFILL_TW_QKV") ? atoi(getenv("NVLLM_GEMM_PREFILL_TW_QKV")) : 0;   // the same for q/k/v only
+    if (shape == 3 && a.e.kind == GemmEpilogue::ROPE_KV && tw_qkv_env >= 2 && tw_qkv_env <= 4) tw = tw_qkv_env;
     const int tiles_t = cdiv(a.Tb, 2 * tw);
     const int total = tiles_n * tiles_t;
     int nbuf;
