@@ -210,5 +210,5 @@ def test_a_rank_left_alone_by_its_peers_stops_with_a_message(tmp_path, tmp_model
     text = out.stdout + out.stderr
     assert "LONELY waited" in text and "LONELY still alive" not in text, text[-3000:]
     waited = float(text.split("LONELY waited")[1].split()[0])
-    assert 1.5 < waited < 8.0, waited          # one wait of 2 s (phase A), not one per call and phase
+    assert 1.5 < waited < 5.5, waited          # one wait of 2 s (phase A); three calls x two phases sat out in full would be 12 s
     assert "waited 2 s for a flag" in text, text[-3000:]
