@@ -478,8 +478,9 @@ void launch_softmax(float* x, int n) {
 // ties resolve to the lowest index).
 // `pairs` (optional): instead of the index, (maximum, index_base + index as a float) per row --
 // what a tensor-parallel rank contributes for its slice of the vocabulary.
+// `out_host` (optional): the index also goes to that page-locked host array, so that no copy follows.
 __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const float* __restrict__ logits, int V, int ld,
-                                                 float2* __restrict__ pairs, int index_base) {
+                                                 float2* __restrict__ pairs, int index_base, int* __restrict__ out_host = nullptr) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const float* row = logits + (size_t)blockIdx.x * ld;
@@ -547,23 +548,26 @@ __global__ __launch_bounds__(1024) void k_argmax(int* __restrict__ out, const fl
             idx = 0;
         }
         if (pairs) pairs[blockIdx.x] = make_float2(V > 0 ? best : -INFINITY, (float)(index_base + idx));
-        else out[blockIdx.x] = idx;
+        else {
+            out[blockIdx.x] = idx;
+            if (out_host) __hip_atomic_store(out_host + blockIdx.x, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 void launch_argmax(int* out, const float* logits, int B, int V) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
-    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, V, (float2*)nullptr, 0);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, V, (float2*)nullptr, 0, (int*)nullptr);
 }
-void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld) {
+void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld, int* out_host) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * V * 4.0, 0);
-    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, ld, (float2*)nullptr, 0);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, out, logits, V, ld, (float2*)nullptr, 0, out_host);
 }
 void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)B * n_valid * 4.0, 0);
-    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, (int*)nullptr, logits, n_valid, ld, pairs, index_base);
+    NVLLM_LAUNCH(k_argmax, dim3(B), dim3(1024), 0, (int*)nullptr, logits, n_valid, ld, pairs, index_base, (int*)nullptr);
 }
 
 // The ranks' (maximum, index) pairs, gathered as [rank][row]: the overall arg-max, lowest index on
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(256) void k_argmax_merge(int* __restrict__ out, con
 }
 // The classifier's per-tile pairs [tile][ld] (gemm_tile.h, F32 epilogue): tiles own ascending index
 // ranges; an index below zero marks a tile that saw nothing but NaN for the row.  One wave per row.
-__global__ __launch_bounds__(256) void k_argmax_tiles(int* __restrict__ out, const float2* __restrict__ pairs, int n_tiles, int B, int ld) {
+__global__ __launch_bounds__(256) void k_argmax_tiles(int* __restrict__ out, const float2* __restrict__ pairs, int n_tiles, int B, int ld,
+                                                      int* __restrict__ out_host) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
@@ -600,12 +605,16 @@ __global__ __launch_bounds__(256) void k_argmax_tiles(int* __restrict__ out, con
             bi = oi;
         }
     }
-    if (lane == 0) out[b] = bi < 0.f ? 0 : (int)bi;   // (nothing but NaN: the reference's scan stays at index 0)
+    if (lane == 0) {
+        const int idx = bi < 0.f ? 0 : (int)bi;   // (nothing but NaN: the reference's scan stays at index 0)
+        out[b] = idx;
+        if (out_host) __hip_atomic_store(out_host + b, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // page-locked host array
+    }
 }
-void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld) {
+void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld, int* out_host) {
     if (B <= 0) return;
     ProfScope ps(PC_ARGMAX, (double)n_tiles * B * 8.0, 0);
-    NVLLM_LAUNCH(k_argmax_tiles, dim3(cdiv(B, 4)), dim3(256), 0, out, pairs, n_tiles, B, ld);
+    NVLLM_LAUNCH(k_argmax_tiles, dim3(cdiv(B, 4)), dim3(256), 0, out, pairs, n_tiles, B, ld, out_host);
 }
 
 void launch_argmax_merge(int* out, const float2* pairs, int W, int B) {

@@ -251,7 +251,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
             ProfScope ps(prof_cls, bytes, 2.0 * T * (double)N * w.K);
             launch_gemm_prefill(a);
         }
-        if (epi.kind == GemmEpilogue::F32 && epi.amax_out) launch_argmax_ld(epi.amax_out, epi.out, T, N, epi.ldo);
+        if (epi.kind == GemmEpilogue::F32 && epi.amax_out) launch_argmax_ld(epi.amax_out, epi.out, T, N, epi.ldo, epi.amax_out_host);
         return a.ksplit;
     }
     const GemmPlan pl = gemm_plan(N, w.K, T, epi.kind, force_ksplit, max_counters, wsp ? wsp->slab_bytes : 0);
@@ -299,7 +299,7 @@ int launch_gemm(const WeightEntry& w, const __half* tiles, int N, const __half* 
     }
     }
     // the tiles' (maximum, index) pairs -> one index per row (tiles that are grid padding wrote nothing)
-    if (amax) launch_argmax_tiles(epi.amax_out, epi.amax_pairs, cdiv(a.NB, nbw), T, epi.amax_ld);
+    if (amax) launch_argmax_tiles(epi.amax_out, epi.amax_pairs, cdiv(a.NB, nbw), T, epi.amax_ld, epi.amax_out_host);
     return ks;
 }
 

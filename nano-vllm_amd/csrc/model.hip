@@ -145,9 +145,10 @@ static void tp_gather_logits(float* full, const float* local, int rows, int slic
 // End of a forward pass: the copies that carry its results to the host are enqueued behind its
 // kernels and an event behind them; returns the pass's ticket.  `view` arrives with the tensor-parallel
 // fields set.
-static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V, PassView view, bool chained = false) {
-    const long ticket = g_next_ticket++;
-    PassSlot& slot = g_pass[ticket % PASS_RING];
+// The slot the next finish_pass will use, with room for B indices: a pass whose arg-max kernel writes the
+// indices into the slot's page-locked array itself needs the address before that kernel is launched.
+static PassSlot& next_slot(int B) {
+    PassSlot& slot = g_pass[g_next_ticket % PASS_RING];
     if (slot.ticket >= 0) NVLLM_FATAL("forward pass %ld was never collected: at most %d passes may be in flight", slot.ticket, PASS_RING);
     // the slot's previous pass (PASS_RING passes ago) ends here: nobody may go on reading its indices
     if (g_seen.argmax == slot.host) g_seen = PassView{};
@@ -157,6 +158,14 @@ static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int 
         HIP_CHECK(hipHostMalloc((void**)&slot.host, (size_t)slot.cap * sizeof(int), hipHostMallocDefault));
     }
     if (!slot.ev) HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    return slot;
+}
+
+// `host_written`: the pass's last kernel has stored the indices into next_slot(B).host itself.
+static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int V, PassView view, bool chained = false,
+                        bool host_written = false) {
+    PassSlot& slot = next_slot(B);
+    const long ticket = g_next_ticket++;
     hipStream_t stream = rt().stream;
     if (rt().logits_mode == NVLLM_LOGITS_HOST) {
         if (!rt().copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&rt().copy_stream, hipStreamNonBlocking));
@@ -166,7 +175,9 @@ static long finish_pass(RunState* s, float* d_logits, int* d_argmax, int B, int 
         HIP_CHECK(hipStreamWaitEvent(stream, g_kernels_done, 0));
     }
     // (with the status word of a one-launch step, which sits right behind the indices)
-    HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)(B + (chained ? 1 : 0)) * sizeof(int), hipMemcpyDeviceToHost, stream));
+    // (a copy operation between two passes costs the stream ~10 us: the copy kernel and the switch around it)
+    if (!host_written)
+        HIP_CHECK(hipMemcpyAsync(slot.host, d_argmax, (size_t)(B + (chained ? 1 : 0)) * sizeof(int), hipMemcpyDeviceToHost, stream));
     slot.chained = chained;
     if (rt().logits_mode == NVLLM_LOGITS_HOST)
         HIP_CHECK(hipMemcpyAsync(s->logits, d_logits, (size_t)B * V * sizeof(float), hipMemcpyDeviceToHost, stream));
@@ -786,6 +797,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
     e5.kind = GemmEpilogue::F32;
     e5.ss_in = ss_head; e5.ss_tiles = ssn; e5.d_in = D; e5.eps = eps;
     PassView view;
+    bool host_written = false;
     // no K split for the classifier (tens of thousands of rows fill the chip); from 112 output rows the
     // launcher may take the dense-tile kernel instead (0 = its own choice)
     const int head_split = B >= 112 ? 0 : 1;
@@ -796,6 +808,10 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         // the classifier's tiles also report their (maximum, index) pairs: the greedy token comes from
         // a merge of those instead of a second pass over the logits
         e5.amax_out = d_argmax;
+        // only token ids leave the GPU: the kernel that picks them also stores them into the pass's page-locked array
+        static const int direct_env = getenv("NVLLM_ARGMAX_DIRECT") ? atoi(getenv("NVLLM_ARGMAX_DIRECT")) : 1;
+        host_written = direct_env && rt().logits_mode == NVLLM_LOGITS_ARGMAX && !chained;
+        if (host_written) e5.amax_out_host = next_slot(B).host;
         e5.amax_ld = (B + 63) & ~63;
         e5.amax_pairs = (float2*)ws_get(WS_AMAX_PAIRS, (size_t)cdiv(V, 32) * e5.amax_ld * sizeof(float2));
         launch_gemm(wh, m->head, V, a16_head, B, e5, head_split, PC_GEMM_HEAD);
@@ -826,7 +842,7 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
         }
     }
 
-    return finish_pass(s, d_logits, d_argmax, B, V, view, chained);
+    return finish_pass(s, d_logits, d_argmax, B, V, view, chained, host_written);
 }
 
 void transformer_batch(int* tokens, int num_tokens, int* pos_arr, int* seq_ids, int* output_indices,

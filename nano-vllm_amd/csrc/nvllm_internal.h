@@ -202,6 +202,7 @@ struct GemmEpilogue {
     // rule, reference sampler.c:86-97) -> amax_out[t].  Every tile leaves one (maximum, index) pair per
     // token in amax_pairs[tile][amax_ld] (room for cdiv(N, 32) tiles), a small launch merges them.
     int* amax_out = nullptr;
+    int* amax_out_host = nullptr;   // optional: the indices also go straight to this page-locked host array (no copy follows)
     float2* amax_pairs = nullptr;
     int amax_ld = 0;
     // SWIGLU_A16 / RESID_A16: fp16 hi/lo tiles for the next projection
@@ -371,8 +372,8 @@ void launch_argmax(int* out, const float* logits, int B, int V);
 // gathered vocabulary slices [rank][row][Vl] into logits rows [row][V]
 void launch_argmax_pairs(float2* pairs, const float* logits, int B, int n_valid, int ld, int index_base);
 void launch_argmax_merge(int* out, const float2* pairs, int W, int B);
-void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld);   // rows `ld` floats apart
-void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld);
+void launch_argmax_ld(int* out, const float* logits, int B, int V, int ld, int* out_host = nullptr);   // rows `ld` floats apart; out_host: also to that page-locked host array
+void launch_argmax_tiles(int* out, const float2* pairs, int n_tiles, int B, int ld, int* out_host = nullptr);
 void launch_logits_unshard(float* full, const float* parts, int W, int B, int Vl, int V);
 // probs = softmax(logits / temperature) per row; cutoff >= 0 also compacts the entries >= cutoff, in
 // index order, into cand[row][0..cap) and counts them (count may exceed cap: the row did not fit)
