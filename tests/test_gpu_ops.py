@@ -332,6 +332,48 @@ def test_attention_at_the_benchmark_shape(hip, oracle, kv_bytes, lo, hi):
         po.close()
 
 
+@pytest.mark.parametrize("n_seqs,H,KVH,hd,ctx_lo,ctx_hi", [
+    (160, 8, 4, 64, 40, 300),      # 640 items: three key slices per item -> the four waves of a workgroup, merged in LDS
+    (96, 6, 6, 48, 17, 200),       # 576 items, head width 48 (dims past 48 idle in the merge), contexts from two pages
+    (40, 32, 8, 128, 100, 700),    # 320 items: six slices -> eight waves per workgroup, two 64-dim halves per lane
+    (70, 4, 2, 32, 1, 64),         # 140 items of one to four pages: slices mostly empty
+    (3, 8, 2, 64, 2000, 2100),     # 6 items: more than eight slices each -> partials in memory and the merge launch
+])
+def test_fp32_row_attention_in_every_slice_form(hip, oracle, n_seqs, H, KVH, hd, ctx_lo, ctx_hi):
+    """The fp32-row attention cuts an item's keys into slices until the chip is full; 2-8 slices of an item share a
+    workgroup (4 or 8 waves) and meet in LDS, more than 8 leave partials in memory for a second launch.  One decode
+    token per sequence over scattered tables, against the oracle."""
+    r = rng(n_seqs * 1000 + hd)
+    L, bs, S = 1, 16, 2112
+    ctx = [int(c) for c in r.integers(ctx_lo, ctx_hi + 1, size=n_seqs)]
+    ctx[0], ctx[-1] = ctx_lo, ctx_hi
+    maxb = S // bs
+    nb = sum((c + bs - 1) // bs for c in ctx) + 5
+    ph, po = _pools(hip, oracle, bs, nb, L, KVH, hd, n_seqs, maxb)
+    try:
+        perm = r.permutation(nb)
+        cur = 0
+        for s_, c in enumerate(ctx):
+            need = (c + bs - 1) // bs
+            blocks = perm[cur:cur + need].tolist()
+            cur += need
+            ph.set_table(s_, blocks)
+            po.set_table(s_, blocks)
+        kfill = r.standard_normal(ph.elems()).astype(np.float32)
+        vfill = r.standard_normal(ph.elems()).astype(np.float32)
+        ph.fill(kfill, vfill)
+        po.fill(kfill, vfill)
+        pos = [c - 1 for c in ctx]
+        sid = list(range(n_seqs))
+        q = r.standard_normal((n_seqs, H * hd)).astype(np.float32)
+        want = util.op_paged_attention_batch(oracle, po, q, 0, pos, sid, S, H, KVH, hd)
+        got = util.op_paged_attention_batch(hip, ph, q, 0, pos, sid, S, H, KVH, hd)
+        np.testing.assert_allclose(got, want, rtol=0, atol=4e-6 * np.abs(want).max() + 2e-6)
+    finally:
+        ph.close()
+        po.close()
+
+
 @pytest.mark.parametrize("bs", [32, 64])
 def test_paged_attention_with_larger_blocks_of_fp32_rows(hip, oracle, bs):
     """The reference's pool takes any block size (memory.c:74-82); the library's fp32 rows take 16, 32, 64 ...:
