@@ -225,7 +225,7 @@ void peer_allreduce(void*, float* buf, size_t count, void* stream) {
 
 }  // namespace
 
-// (tp.hip) the session ends: unmap the peers' segments; this rank's own stays allocated until a new handle is asked for
+// (tp.hip) the session ends: unmap the peers' segments; this rank's own stays allocated (a peer may still be reading it)
 void tp_peer_finalize() {
     PeerState& s = g_peer;
     if (!s.active) return;
@@ -252,8 +252,10 @@ int nvllm_tp_peer_handle(void* handle) {
         fprintf(stderr, "nvllm: the peer exchange is in use; call nvllm_tp_finalize first\n");
         return -1;
     }
-    if (s.own && s.own_in_use) {   // the last session's segment: every peer has unmapped it by now (they ask for new handles too)
-        HIP_CHECK(hipFree(s.own));
+    if (s.own && s.own_in_use) {
+        // The last session's segment is retired, not freed: this rank's last all-reduce ended when every peer had
+        // raised its second flag, but a peer may still be reading this rank's result slice, and nothing here tells
+        // when it has finished.  12.6 MiB stay allocated per past session until the process ends.
         s.own = nullptr;
     }
     if (!s.own) {
