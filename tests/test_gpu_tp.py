@@ -164,6 +164,8 @@ def test_setup_is_refused_twice_and_for_bad_placements(hip):
     (2, 2, GQA, "peer"),                   # the library's own exchange: kernels that store into each other's segments
     (4, 4, GQA, "peer"),
     (2, 4, LLAMA7B_LAYER, "peer"),
+    (8, 4, dict(dim=512, hidden_dim=512, n_layers=2, n_heads=8, n_kv_heads=8, vocab_size=600, max_seq_len=160), "peer"),
+                                           # BASELINE.json configs[4]'s degree: eight ranks, one head of 64 and 64 hidden columns each
 ])
 def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_bytes, over, exchange):
     """`world` processes, each with its slice of the weights and of the KV pool; the exchange
@@ -174,7 +176,7 @@ def test_ranks_sharing_one_gpu_match_the_oracle(tmp_path, tmp_models, world, kv_
     big = over.get("dim", 0) >= 4096
     spec = dict(name="tiny", over=over, model_path=path, n_seqs=3 if big else 5, seed=23, n_new=8 if big else 16, chunk=12,
                 kv_bytes=kv_bytes, out_dir=str(tmp_path), exchange=exchange)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else "2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if big else ("1" if world > 4 else "2"), HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = 29620 + world + kv_bytes + (40 if big else 0) + (100 if exchange == "peer" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
