@@ -158,8 +158,12 @@ __global__ __launch_bounds__(NSW == 8 ? 512 : 256) void k_paged_attn(AttnKArgs a
             sc[rr] = (kfirst + rr <= plim) ? v : -INFINITY;
             mx = fmaxf(mx, sc[rr]);
         }
+#ifdef NVLLM_ATTN_SHFL_MAX
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#else
+        mx = rows_max(mx);
+#endif
         if (__any(mx > m)) {   // the running maximum of some column rises: rescale (rare after the first pages)
             const float mn = fmaxf(m, mx);
             const float alpha = mn == -INFINITY ? 1.f : expf(m - mn);

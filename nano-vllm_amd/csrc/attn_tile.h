@@ -43,6 +43,18 @@ struct AttnKArgs {
 
 __device__ __forceinline__ ah4_t as_ah4(au2_t v) { return __builtin_bit_cast(ah4_t, v); }
 
+// Maximum / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), the result in all four:
+// two row swaps in the vector unit (v_permlane32_swap, v_permlane16_swap: rows 2,3 <-> 0,1 of a copy, then odd
+// <-> even rows) instead of two trips through the LDS crossbar per reduction.
+__device__ __forceinline__ float rows_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float m = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned v = __builtin_bit_cast(unsigned, m);
+    const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+
 // LDS an item's four waves need to merge: (max, sum) per wave and column, accumulators per wave
 template <int HD>
 constexpr int attn16_lds() {
@@ -197,8 +209,12 @@ struct Attn16Wave {
             sc[rr] = (kfirst + rr <= plim) ? v : -INFINITY;
             mx = fmaxf(mx, sc[rr]);
         }
+#ifdef NVLLM_ATTN_SHFL_MAX
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#else
+        mx = rows_max(mx);
+#endif
         if (__any(mx > m)) {   // some column's running maximum rises (rare after the first pages)
             const float mn = fmaxf(m, mx);
             const float alpha = mn == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(m - mn);
