@@ -150,7 +150,6 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     RedTile* red = reinterpret_cast<RedTile*>(lds_dyn);
     float* s_rinv = reinterpret_cast<float*>(lds_dyn + NW * NBW * TB * 64 * 16);   // [TB * 16]
     float (*s_part)[TB * 16] = reinterpret_cast<float (*)[TB * 16]>(s_rinv + TB * 16);   // [PARTS][TB * 16]
-    float (*s_ss)[TB * 16] = reinterpret_cast<float (*)[TB * 16]>(s_rinv + TB * 16 + NW * 64);   // [2][TB * 16]
     unsigned* s_ticket = reinterpret_cast<unsigned*>(s_rinv + TB * 16 + NW * 64 + 2 * TB * 16);
 
     const int lane = tid & 63;
@@ -419,19 +418,21 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     for (int h = 0; h < ROUNDS; h++)
 #pragma unroll
         for (int q = 0; q < IPT; q++) ssq[h][q] = 0.f;
+    if (EPI == GemmEpilogue::SWIGLU_A16) {
+        // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads: swap through LDS so that
+        // the i = 0 thread has both.  All rounds at once, each in its own part of the array (the partial tiles
+        // in it have been consumed: a barrier back), so one barrier serves them all.
 #pragma unroll
-    for (int h = 0; h < ROUNDS; h++) {
-        if (EPI == GemmEpilogue::SWIGLU_A16) {
-            // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads:
-            // swap through LDS so that the i = 0 thread has both
-            __syncthreads();
+        for (int h = 0; h < ROUNDS; h++)
 #pragma unroll
             for (int q = 0; q < IPT; q++) {
                 const int e = tid + q * NW * 64;
-                if (e < ITEMS) red[0][(e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
+                if (e < ITEMS) red[0][2 * h + (e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
             }
-            __syncthreads();
-        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < ROUNDS; h++) {
 #pragma unroll
         for (int q = 0; q < IPT; q++) {
             const int e = tid + q * NW * 64;
@@ -478,7 +479,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                 }
             } else if (EPI == GemmEpilogue::SWIGLU_A16) {
                 if (i == 0 && live) {
-                    const f4_t u = red[0][1][j][l];
+                    const f4_t u = red[0][2 * h + 1][j][l];
                     float z[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) z[r] = silu_mul(y[r], u[r] * rinv);
@@ -564,23 +565,27 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
         // per-token sum of x^2 over each 32-feature group (= one round: two row blocks):
         // over the 4 lane groups (l>>4), then over the round's two row blocks (i)
         const int ss_cols = (p.N + 31) >> 5;
+        // all rounds' halves meet in the array of the partial tiles (consumed: a barrier back), [round][half][token]:
+        // one barrier for all rounds
+        float (*ss_lds)[2][TB * 16] = reinterpret_cast<float (*)[2][TB * 16]>(lds_dyn);
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++) {
-            __syncthreads();
+        for (int h = 0; h < ROUNDS; h++)
 #pragma unroll
             for (int q = 0; q < IPT; q++) {
                 float sq = ssq[h][q];
                 sq += __shfl_xor(sq, 16, 64);
                 sq += __shfl_xor(sq, 32, 64);
                 const int e = tid + q * NW * 64;
-                if (e < ITEMS && (e & 63) < 16) s_ss[(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
+                if (e < ITEMS && (e & 63) < 16) ss_lds[h][(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
             }
-            __syncthreads();
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < ROUNDS; h++) {
             if (tid < TB * 16) {
                 const int t = tb0 * 16 + tid;
                 const int col = ix.x * ROUNDS + h;
                 if (t < p.T && col < ss_cols) {
-                    const float sum = s_ss[0][tid] + s_ss[1][tid];
+                    const float sum = ss_lds[h][0][tid] + ss_lds[h][1][tid];
                     if constexpr (COH)
                         __hip_atomic_store(reinterpret_cast<unsigned*>(ep.ss_out + (size_t)t * ss_cols + col),
                                            __builtin_bit_cast(unsigned, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
