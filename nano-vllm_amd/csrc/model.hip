@@ -752,8 +752,10 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
             e2.kind = GemmEpilogue::F32;
             e2.out = s->xb; e2.ldo = D;
             launch_gemm(wwo, lp.wo, D, a16_att, T, e2, 0, PC_GEMM_WO);
-            tp_allreduce(s->xb, (size_t)T * D);
-            launch_resid_prescale(s->x, s->xb, a16_x, ss_b, lp.rms_ffn, T, D);
+            if (!tp_peer_allreduce_resid(s->xb, s->x, a16_x, ss_b, lp.rms_ffn, T, D)) {
+                tp_allreduce(s->xb, (size_t)T * D);
+                launch_resid_prescale(s->x, s->xb, a16_x, ss_b, lp.rms_ffn, T, D);
+            }
         }
         // hb = silu(rmsnorm(x).w_gate^T) * (rmsnorm(x).w_up^T)                    (model.c:388-391)
         WeightEntry wgu{lp.gateup, 2 * F, D, D / 32, (long)(D / 32) * TILE_HALVES, nullptr};
@@ -776,8 +778,10 @@ static long enqueue_pass(int* tokens, int num_tokens, int* pos_arr, int* seq_ids
             e4.kind = GemmEpilogue::F32;
             e4.out = s->xb; e4.ldo = D;
             launch_gemm(wdn, lp.down, D, a16_h, T, e4, 0, PC_GEMM_DOWN);
-            tp_allreduce(s->xb, (size_t)T * D);
-            launch_resid_prescale(s->x, s->xb, a16_x, ss_a, gain_next, T, D);
+            if (!tp_peer_allreduce_resid(s->xb, s->x, a16_x, ss_a, gain_next, T, D)) {
+                tp_allreduce(s->xb, (size_t)T * D);
+                launch_resid_prescale(s->x, s->xb, a16_x, ss_a, gain_next, T, D);
+            }
         }
     }
     // logits only for the rows named by output_indices                            (model.c:396,411-418)

@@ -103,6 +103,9 @@ TpState& tp();
 void tp_allreduce(float* buf, size_t count);   // in place, on the library stream
 // recv[r * count .. ) = rank r's `count` floats at send, on every rank (send must not overlap recv)
 void tp_allgather(const float* send, float* recv, size_t count);
+// tp_peer.hip: the all-reduce of [T, D] partial sums with the residual tail (x += sum; a16 = x * gain tiles; ss) in its
+// last phases; false = not available (no peer session of several ranks): all-reduce, then launch_resid_prescale
+bool tp_peer_allreduce_resid(float* partial, float* x, __half* a16, float* ss, const float* gain, int T, int D);
 void tp_peer_finalize();   // tp_peer.hip: unmaps the other ranks' exchange segments (no-op without a peer session)
 
 // Grow-only device scratch, one buffer per slot.

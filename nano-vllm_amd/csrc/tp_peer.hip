@@ -21,6 +21,11 @@
 // serial's parity, and a rank can be at most one call ahead of any peer (it cannot finish call s
 // without every peer's B(s)), so no buffer is overwritten while somebody still reads it.
 //
+// The kernel that follows every such all-reduce in the forward pass -- x += sum, x times the next norm's gain as
+// fp16 tiles, sums of squares per 32 features -- can ride in phases B and C (RESID): every element of the sum
+// already passes through a lane there, eight consecutive features at a time, so the sum never goes back to the
+// caller's buffer and the stand-alone kernel (and its launch) is not needed.
+//
 // Memory: the segment is allocated uncached (fine-grained), as RCCL allocates the buffers it
 // shares between processes; every access to it carries system scope (sc0 sc1) and data is fenced
 // at system scope before a flag is raised.  A wait that does not end (a peer that never launches)
@@ -28,6 +33,7 @@
 // page-locked host memory: the launch still ends, and the next call on the host stops the process
 // with a message.
 #include "nvllm_internal.h"
+#include "resid_tail.h"
 
 #include <cstring>
 
@@ -67,6 +73,12 @@ struct PeerArgs {
     unsigned* status;    // page-locked host word: non-zero = a wait ran out
     unsigned wgs;        // workgroups of the launch (a power of two, the same for every launch of a session)
     unsigned long long wait_ticks;   // how long a wait may last
+    // RESID: what the sums are added to (see resid_tail.h); `base` = index of buf[0] in the whole [tokens, D] array
+    float* x;
+    __half* a16;
+    float* ss;
+    const float* gain;
+    unsigned D, base;
 };
 
 __device__ __forceinline__ unsigned* flag_of(unsigned char* seg, int phase, int parity, int src) {
@@ -120,6 +132,19 @@ __device__ __forceinline__ void wait_all(const PeerArgs& a, int phase, int parit
     __syncthreads();
 }
 
+// eight sums (features E .. E+7 of the flat [tokens, D] array) -> the residual tail; the four lanes of a 32-feature
+// group are active together (slices and pieces are cut at multiples of 32)
+__device__ __forceinline__ void peer_resid_8(const PeerArgs& a, unsigned E, pf4_t b0, pf4_t b1) {
+    const unsigned t = E / a.D, i = E - t * a.D;
+    const unsigned Kb = a.D >> 5;
+    float part = resid_tail_8(a.x + (size_t)t * a.D, make_float4(b0[0], b0[1], b0[2], b0[3]), make_float4(b1[0], b1[1], b1[2], b1[3]),
+                              a.a16, a.gain, (int)t, (int)i, (int)Kb);
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    if ((threadIdx.x & 3) == 0) a.ss[(size_t)t * Kb + (i >> 5)] = part;
+}
+
+template <bool RESID>
 __global__ __launch_bounds__(PEER_THREADS) void k_peer_allreduce(PeerArgs a) {
     const int parity = (int)(a.serial & 1u);
     const unsigned tid = blockIdx.x * PEER_THREADS + threadIdx.x;
@@ -145,7 +170,7 @@ __global__ __launch_bounds__(PEER_THREADS) void k_peer_allreduce(PeerArgs a) {
         const __amdgpu_buffer_rsrc_t rs = seg_rsrc(a.seg[a.rank]);
         const unsigned stage0 = (unsigned)STAGE_OFF + ((unsigned)parity * (unsigned)STAGE_FLOATS) * 4u;
         const unsigned red0 = (unsigned)RED_OFF + ((unsigned)parity * (unsigned)RED_FLOATS) * 4u;
-        for (unsigned e = 4 * tid; e < hi - lo; e += 4 * nthr) {
+        auto sum4 = [&](unsigned e) {
             pf4_t part[PEER_MAX_WORLD];
 #pragma unroll
             for (int i = 0; i < PEER_MAX_WORLD; i++)
@@ -156,7 +181,15 @@ __global__ __launch_bounds__(PEER_THREADS) void k_peer_allreduce(PeerArgs a) {
             for (int i = 1; i < PEER_MAX_WORLD; i++)
                 if (i < a.world) sum += part[i];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu4_t, sum), rs, (int)(red0 + e * 4u), 0, AUX_SYS);
-            *reinterpret_cast<pf4_t*>(a.buf + lo + e) = sum;
+            return sum;
+        };
+        if constexpr (RESID) {
+            for (unsigned e = 8 * tid; e < hi - lo; e += 8 * nthr) {
+                const pf4_t b0 = sum4(e), b1 = sum4(e + 4);
+                peer_resid_8(a, a.base + lo + e, b0, b1);
+            }
+        } else {
+            for (unsigned e = 4 * tid; e < hi - lo; e += 4 * nthr) *reinterpret_cast<pf4_t*>(a.buf + lo + e) = sum4(e);
         }
     }
     arrive_and_publish(a, 1, parity);
@@ -168,9 +201,17 @@ __global__ __launch_bounds__(PEER_THREADS) void k_peer_allreduce(PeerArgs a) {
         const unsigned lo = min(a.count, (unsigned)j * a.per), hi = min(a.count, lo + a.per);
         const __amdgpu_buffer_rsrc_t rs = seg_rsrc(a.seg[j]);
         const unsigned red0 = (unsigned)RED_OFF + ((unsigned)parity * (unsigned)RED_FLOATS) * 4u;
-        for (unsigned e = 4 * tid; e < hi - lo; e += 4 * nthr)
-            *reinterpret_cast<pf4_t*>(a.buf + lo + e) =
-                __builtin_bit_cast(pf4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(red0 + e * 4u), 0, AUX_SYS));
+        if constexpr (RESID) {
+            for (unsigned e = 8 * tid; e < hi - lo; e += 8 * nthr) {
+                const pf4_t b0 = __builtin_bit_cast(pf4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(red0 + e * 4u), 0, AUX_SYS));
+                const pf4_t b1 = __builtin_bit_cast(pf4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(red0 + (e + 4) * 4u), 0, AUX_SYS));
+                peer_resid_8(a, a.base + lo + e, b0, b1);
+            }
+        } else {
+            for (unsigned e = 4 * tid; e < hi - lo; e += 4 * nthr)
+                *reinterpret_cast<pf4_t*>(a.buf + lo + e) =
+                    __builtin_bit_cast(pf4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(red0 + e * 4u), 0, AUX_SYS));
+        }
     }
 }
 
@@ -196,19 +237,28 @@ void peer_check() {
                     "do not make the same calls)", g_peer.rank, g_peer.wait_s, *g_peer.status - 1u);
 }
 
-void peer_allreduce(void*, float* buf, size_t count, void* stream) {
+struct PeerResid {   // what a RESID call adds its sums to
+    float* x;
+    __half* a16;
+    float* ss;
+    const float* gain;
+    int D;
+};
+
+void peer_exchange(float* buf, size_t count, void* stream, const PeerResid* resid) {
     PeerState& s = g_peer;
     peer_check();
     s.calls++;
     s.floats += count;
     if (s.world == 1 || count == 0) return;
-    if (count % 4 != 0) NVLLM_FATAL("tensor-parallel peer exchange: %zu floats is not a multiple of 4", count);
+    const size_t grain = resid ? 32 : 4;   // slices end at whole granules (RESID: whole 32-feature groups)
+    if (count % grain != 0) NVLLM_FATAL("tensor-parallel peer exchange: %zu floats is not a multiple of %zu", count, grain);
     for (size_t done = 0; done < count;) {
         const size_t n = count - done < PEER_MAX_FLOATS ? count - done : PEER_MAX_FLOATS;
         PeerArgs a;
         a.buf = buf + done;
         a.count = (unsigned)n;
-        a.per = (unsigned)(((n + s.world - 1) / s.world + 3) / 4 * 4);
+        a.per = (unsigned)(((n + s.world - 1) / s.world + grain - 1) / grain * grain);
         a.rank = s.rank;
         a.world = s.world;
         a.serial = ++s.serial;
@@ -217,13 +267,35 @@ void peer_allreduce(void*, float* buf, size_t count, void* stream) {
         a.status = s.status;
         a.wgs = s.wgs;
         a.wait_ticks = (unsigned long long)s.wait_s * PEER_TICKS_PER_S;
-        hipLaunchKernelGGL(k_peer_allreduce, dim3(s.wgs), dim3(PEER_THREADS), 0, (hipStream_t)stream, a);
+        a.x = resid ? resid->x : nullptr;
+        a.a16 = resid ? resid->a16 : nullptr;
+        a.ss = resid ? resid->ss : nullptr;
+        a.gain = resid ? resid->gain : nullptr;
+        a.D = resid ? (unsigned)resid->D : 1u;
+        a.base = (unsigned)done;
+        if (resid) hipLaunchKernelGGL(k_peer_allreduce<true>, dim3(s.wgs), dim3(PEER_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_peer_allreduce<false>, dim3(s.wgs), dim3(PEER_THREADS), 0, (hipStream_t)stream, a);
         HIP_CHECK(hipGetLastError());
         done += n;
     }
 }
 
+void peer_allreduce(void*, float* buf, size_t count, void* stream) { peer_exchange(buf, count, stream, nullptr); }
+
 }  // namespace
+
+// (tp.hip) The all-reduce of the partial sums at `partial` ([T, D], this rank's) with the residual tail in its last
+// phases: x += sum, a16 = (x * gain) tiles, ss = sums of squares per 32 features.  False: no peer session with more
+// than one rank (or a width the tail does not take) -- the caller all-reduces and runs the tail as its own kernel.
+bool tp_peer_allreduce_resid(float* partial, float* x, __half* a16, float* ss, const float* gain, int T, int D) {
+    PeerState& s = g_peer;
+    static const int fused_env = getenv("NVLLM_TP_PEER_FUSED") ? atoi(getenv("NVLLM_TP_PEER_FUSED")) : 1;
+    if (!s.active || s.world == 1 || !fused_env || D % 32 != 0 || T <= 0) return false;
+    if ((size_t)T * D >= (1ull << 32)) return false;
+    const PeerResid r{x, a16, ss, gain, D};
+    peer_exchange(partial, (size_t)T * D, (void*)rt().stream, &r);
+    return true;
+}
 
 // (tp.hip) the session ends: unmap the peers' segments; this rank's own stays allocated (a peer may still be reading it)
 void tp_peer_finalize() {

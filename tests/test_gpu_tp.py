@@ -217,3 +217,27 @@ def test_a_rank_left_alone_by_its_peers_stops_with_a_message(tmp_path, tmp_model
     waited = float(text.split("LONELY waited")[1].split()[0])
     assert 1.5 < waited < 5.5, waited          # one wait of 2 s (phase A); three calls x two phases sat out in full would be 12 s
     assert "waited 2 s for a flag" in text, text[-3000:]
+
+
+def test_residual_tail_inside_the_peer_exchange_gives_the_same_bits(tmp_path, tmp_models):
+    """The kernel that follows each all-reduce (x += sum, the next projection's input tiles, sums of squares) rides in the
+    peer exchange's last phases by default; NVLLM_TP_PEER_FUSED=0 keeps it a kernel of its own.  Two ranks, both ways:
+    every logit of every step must be the same bits."""
+    path, shape = tmp_models("tiny", seed=5, **GQA)
+    crcs = []
+    for fused in ("1", "0"):
+        out_dir = tmp_path / f"fused{fused}"
+        out_dir.mkdir()
+        spec = dict(name="tiny", over=GQA, model_path=path, n_seqs=4, seed=23, n_new=12, chunk=12, kv_bytes=2, out_dir=str(out_dir),
+                    exchange="peer", probe_counts=[1000])
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", NVLLM_TP_PEER_FUSED=fused)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(29795 + int(fused)),
+                              os.path.join(ROOT, "tests", "tp_worker.py"), json.dumps(spec)],
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+        rs = [json.load(open(out_dir / f"rank{rank}.json")) for rank in range(2)]
+        assert all(r["same_tokens"] and r["same_trace"] for r in rs), rs
+        assert rs[0]["logits_crc"] == rs[1]["logits_crc"]          # the ranks hold the same logits
+        crcs.append(rs[0]["logits_crc"])
+    assert crcs[0] == crcs[1], crcs

@@ -141,7 +141,8 @@ def main():
                same_argmax=bool(same_argmax), same_sampled=bool(same_sampled),
                allreduce_calls=reduce_calls, allreduce_floats=reduce_floats, steps=len(want["steps"]),
                tokens_forwarded=tokens_forwarded, n_layers=shape.n_layers, dim=shape.dim,
-               output_rows=rows, vocab_slice=sh.vocab_slice, vocab=[sh.vocab0, sh.vocab], allreduce_us_128x4096=timing)
+               output_rows=rows, vocab_slice=sh.vocab_slice, vocab=[sh.vocab0, sh.vocab], allreduce_us_128x4096=timing,
+               logits_crc=int(sum(int(np.frombuffer(a["logits"].tobytes(), np.uint32).astype(np.uint64).sum()) for a in got["steps"]) % (1 << 61)))
     with open(os.path.join(spec["out_dir"], f"rank{rank}.json"), "w") as f:
         json.dump(out, f)
     dist.barrier()
