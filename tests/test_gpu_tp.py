@@ -158,11 +158,10 @@ def test_setup_is_refused_twice_and_for_bad_placements(hip):
 @pytest.mark.parametrize("world,kv_bytes,over,exchange", [
     (2, 4, dict(hidden_dim=192), "host"),  # "tiny": 4 heads / 2 kv heads of width 16
     (2, 2, GQA, "host"),
-    (4, 4, GQA, "host"),                   # one kv head (two query heads) per rank
     (2, 4, LLAMA7B_LAYER, "host"),         # 16 heads of 128 and 5504 hidden columns per rank (fp32 rows: the sampled-token
                                            # comparison draws from probabilities that must agree to ~1e-6)
     (2, 2, GQA, "peer"),                   # the library's own exchange: kernels that store into each other's segments
-    (4, 4, GQA, "peer"),
+    (4, 4, GQA, "peer"),                   # one kv head (two query heads) per rank
     (2, 4, LLAMA7B_LAYER, "peer"),
     (8, 4, dict(dim=512, hidden_dim=512, n_layers=2, n_heads=8, n_kv_heads=8, vocab_size=600, max_seq_len=160), "peer"),
                                            # BASELINE.json configs[4]'s degree: eight ranks, one head of 64 and 64 hidden columns each
