@@ -143,7 +143,10 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     static_assert(RW % RA == 0, "the activation ring must divide the weight ring");
     constexpr int ROUNDS = NBW / 2;    // LDS reduction rounds, two row blocks each
     constexpr int ITEMS = 2 * TB * 64; // float4 results per round
-    constexpr int IPT = (ITEMS + NW * 64 - 1) / (NW * 64);  // items per thread per round
+    constexpr int WITEMS = ROUNDS * ITEMS;                        // float4 results of the tile: item w = round * ITEMS + e
+    constexpr int FPT = (WITEMS + NW * 64 - 1) / (NW * 64);     // items per thread: thread tid takes w = tid + s * NW*64
+    constexpr int ITEMS_SHIFT = TB == 1 ? 7 : (TB == 2 ? 8 : 9);
+    static_assert((1 << ITEMS_SHIFT) == ITEMS, "2, 4 or 8 row-block x token-block pairs of 64 lanes per round");
     constexpr int PARTS = (NW * 64) / (TB * 16);
     // the waves' partial tiles, all row blocks at once: red[wave][row block][token block][lane]
     typedef f4_t RedTile[NBW][TB][64];
@@ -282,37 +285,36 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
     // only the one that ends up running the epilogue uses them).  Indices are clamped,
     // not predicated: unconditional loads.
     const GemmEpilogue& ep = p.e;
-    float4 pf_x[ROUNDS][IPT], pf_g[ROUNDS][IPT];
+    float4 pf_x[FPT], pf_g[FPT];
     int pf_pos = 0, pf_row = -1;
     __amdgpu_buffer_rsrc_t rs_x = gemm_rsrc(ep.x, (unsigned)p.T * (unsigned)p.N * 4u);
     __amdgpu_buffer_rsrc_t rs_o = gemm_rsrc(ep.a16_out, (unsigned)p.Tb * (unsigned)ep.Kb_out * 2048u);
     __amdgpu_buffer_rsrc_t rs_q = gemm_rsrc(ep.q_out, (unsigned)p.T * (unsigned)ep.QD * 4u);
     if (EPI == GemmEpilogue::RESID_A16) {
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = min(tid + q * NW * 64, ITEMS - 1);
-                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                const int t = min(tb0 * 16 + j * 16 + (l & 15), p.T - 1);
-                const int n = min((nb0 + 2 * h + i) * 16 + 4 * (l >> 4), p.N - 4);
-                if constexpr (COH)
-                    pf_x[h][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (t * p.N + n) * 4, 0, AUX_SC1));
-                else
-                    pf_x[h][q] = *reinterpret_cast<const float4*>(ep.x + (size_t)t * p.N + n);
-                pf_g[h][q] = *reinterpret_cast<const float4*>(ep.gain_next + n);
-            }
+        for (int s = 0; s < FPT; s++) {
+            const int w_ = min(tid + s * NW * 64, WITEMS - 1);
+            const int h = w_ >> ITEMS_SHIFT, e = w_ & (ITEMS - 1);
+            const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+            const int t = min(tb0 * 16 + j * 16 + (l & 15), p.T - 1);
+            const int n = min((nb0 + 2 * h + i) * 16 + 4 * (l >> 4), p.N - 4);
+            if constexpr (COH)
+                pf_x[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (t * p.N + n) * 4, 0, AUX_SC1));
+            else
+                pf_x[s] = *reinterpret_cast<const float4*>(ep.x + (size_t)t * p.N + n);
+            pf_g[s] = *reinterpret_cast<const float4*>(ep.gain_next + n);
+        }
     }
-    if (EPI == GemmEpilogue::ROPE_KV) {   // all items of a thread belong to one token
-        const int e = min(tid, ITEMS - 1);
+    if (EPI == GemmEpilogue::ROPE_KV) {   // all items of a thread belong to one token (NW*64 is a multiple of TB*64)
+        const int e = min(tid, WITEMS - 1) & (ITEMS - 1);
         const int t = min(tb0 * 16 + ((e >> 6) % TB) * 16 + (e & 15), p.T - 1);
         pf_pos = ep.pos[t];
         pf_row = ep.kv_row[t];
     }
     // ---- 1. sum the waves' partial tiles through LDS: every wave stores all its tiles, ONE
-    // barrier, then thread `e` (item e = tid + q * NW*64) collects, per round h (two row
-    // blocks), the float4 for token t(e) and features n(h, e) .. n+3, in wave order.
-    f4_t v[ROUNDS][IPT];
+    // barrier, then each thread collects its items w = (round h, e): the float4 for token t(e) and
+    // features n(h, e) .. n+3, in wave order.  (The items of all rounds are dealt over all threads.)
+    f4_t v[FPT];
 #pragma unroll
     for (int i = 0; i < NBW; i++)
 #pragma unroll
@@ -327,36 +329,31 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
         s_rinv[tid] = __fdiv_rn(1.0f, sqrtf(__fadd_rn(__fdiv_rn(ss, (float)ep.d_in), ep.eps)));
     }
 #pragma unroll
-    for (int h = 0; h < ROUNDS; h++) {
+    for (int s = 0; s < FPT; s++) {
+        const int w_ = tid + s * NW * 64;
+        f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
+        if (w_ < WITEMS) {
+            const int h = w_ >> ITEMS_SHIFT, e = w_ & (ITEMS - 1);
+            const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
+            sum = red[0][2 * h + i][j][l];
 #pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            const int e = tid + q * NW * 64;
-            f4_t sum = f4_t{0.f, 0.f, 0.f, 0.f};
-            if (e < ITEMS) {
-                const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
-                sum = red[0][2 * h + i][j][l];
-#pragma unroll
-                for (int wv = 1; wv < NW; wv++) sum += red[wv][2 * h + i][j][l];
-            }
-            v[h][q] = sum;
+            for (int wv = 1; wv < NW; wv++) sum += red[wv][2 * h + i][j][l];
         }
+        v[s] = sum;
     }
     __syncthreads();   // everybody has read the partial tiles (the epilogue reuses the array) and s_rinv is visible
-    NVLLM_TSTAMP(4, v[ROUNDS - 1][IPT - 1][0]);
+    NVLLM_TSTAMP(4, v[FPT - 1][0]);
     // ---- 2. close the K split: write-through slab, ticket, last arriver reduces.
     const unsigned tile_id = ix.z * ix.gx + ix.x;
     if (p.ksplit > 1) {
         float* my = p.slab + ((size_t)tile_id * p.ksplit + ix.y) * (ROUNDS * ITEMS * 4);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, ROUNDS * ITEMS * 16, 0x00020000);
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = tid + q * NW * 64;
-                if (e < ITEMS)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[h][q]), rs, (h * ITEMS + e) * 16, 0,
-                                                           /*sc1: write through*/ AUX_SC1);
-            }
+        for (int s = 0; s < FPT; s++) {
+            const int w_ = tid + s * NW * 64;
+            if (w_ < WITEMS)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v[s]), rs, w_ * 16, 0, /*sc1: write through*/ AUX_SC1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
         __syncthreads();
         if (tid == 0)
@@ -380,63 +377,53 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
         // Slice indices past the end are clamped (a repeated load), not predicated, so the
         // loads stay unconditional; sums are taken in slice order.
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) v[h][q] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < FPT; s++) v[s] = f4_t{0.f, 0.f, 0.f, 0.f};
         for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
-            f4_t part[ROUNDS][IPT][8];
+            f4_t part[FPT][8];
 #pragma unroll
-            for (int h = 0; h < ROUNDS; h++)
+            for (int s = 0; s < FPT; s++) {
+                const int w_ = min(tid + s * NW * 64, WITEMS - 1);
 #pragma unroll
-                for (int q = 0; q < IPT; q++) {
-                    const int e = min(tid + q * NW * 64, ITEMS - 1);
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int sl = min(s0 + u, p.ksplit - 1);
-                        if (past_l1)
-                            part[h][q][u] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                         rs_all, ((sl * ROUNDS + h) * ITEMS + e) * 16, 0, AUX_SC1));
-                        else
-                            part[h][q][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * ROUNDS * ITEMS + h * ITEMS + e) * 4);
-                    }
+                for (int u = 0; u < 8; u++) {
+                    const int sl = min(s0 + u, p.ksplit - 1);
+                    if (past_l1)
+                        part[s][u] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_all, (sl * WITEMS + w_) * 16, 0, AUX_SC1));
+                    else
+                        part[s][u] = *reinterpret_cast<const f4_t*>(base + ((size_t)sl * WITEMS + w_) * 4);
                 }
+            }
 #pragma unroll
-            for (int h = 0; h < ROUNDS; h++)
+            for (int s = 0; s < FPT; s++)
 #pragma unroll
-                for (int q = 0; q < IPT; q++)
-#pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        if (s0 + u < p.ksplit) v[h][q] += part[h][q][u];
+                for (int u = 0; u < 8; u++)
+                    if (s0 + u < p.ksplit) v[s] += part[s][u];
         }
         // ready for the next launch (nobody else touches this tile's counter any more)
         if (tid == 0) __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    NVLLM_TSTAMP(5, v[ROUNDS - 1][IPT - 1][0]);
+    NVLLM_TSTAMP(5, v[FPT - 1][0]);
     // ---- 3. epilogue on complete sums
-    float ssq[ROUNDS][IPT];
+    float ssq[FPT];
 #pragma unroll
-    for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-        for (int q = 0; q < IPT; q++) ssq[h][q] = 0.f;
+    for (int s = 0; s < FPT; s++) ssq[s] = 0.f;
     if (EPI == GemmEpilogue::SWIGLU_A16) {
         // gate (even row block, i = 0) and up (odd, i = 1) sit in different threads: swap through LDS so that
         // the i = 0 thread has both.  All rounds at once, each in its own part of the array (the partial tiles
         // in it have been consumed: a barrier back), so one barrier serves them all.
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                const int e = tid + q * NW * 64;
-                if (e < ITEMS) red[0][2 * h + (e >> 6) / TB][(e >> 6) % TB][e & 63] = v[h][q];
-            }
+        for (int s = 0; s < FPT; s++) {
+            const int w_ = tid + s * NW * 64;
+            const int h = w_ >> ITEMS_SHIFT, e = w_ & (ITEMS - 1);
+            if (w_ < WITEMS) red[0][2 * h + (e >> 6) / TB][(e >> 6) % TB][e & 63] = v[s];
+        }
         __syncthreads();
     }
+    {
 #pragma unroll
-    for (int h = 0; h < ROUNDS; h++) {
-#pragma unroll
-        for (int q = 0; q < IPT; q++) {
-            const int e = tid + q * NW * 64;
-            if (e >= ITEMS) continue;
+        for (int s = 0; s < FPT; s++) {
+            const int w_ = tid + s * NW * 64;
+            if (w_ >= WITEMS) continue;
+            const int h = w_ >> ITEMS_SHIFT, e = w_ & (ITEMS - 1);
             const int l = e & 63, j = (e >> 6) % TB, i = (e >> 6) / TB;
             const int tl = j * 16 + (l & 15);
             const int t = tb0 * 16 + tl;
@@ -444,7 +431,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
             const int n = nb * 16 + 4 * (l >> 4);
             const bool live = t < p.T && tb0 + j < p.Tb && nb < p.NB;
             const float rinv = ep.ss_in ? s_rinv[tl] : 1.0f;
-            float y[4] = {v[h][q][0] * rinv, v[h][q][1] * rinv, v[h][q][2] * rinv, v[h][q][3] * rinv};
+            float y[4] = {v[s][0] * rinv, v[s][1] * rinv, v[s][2] * rinv, v[s][3] * rinv};
             if (EPI == GemmEpilogue::F32) {
                 if (live) {
                     float* o = ep.out + (size_t)t * ep.ldo + n;
@@ -490,8 +477,8 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
             } else if (EPI == GemmEpilogue::RESID_A16) {
                 if (live) {
                     float* xr = ep.x + (size_t)t * p.N + n;
-                    const float4 xo = pf_x[h][q];
-                    const float4 g = pf_g[h][q];
+                    const float4 xo = pf_x[s];
+                    const float4 g = pf_g[s];
                     // residual add as the reference's accum(): x = x + branch (layers.c:163-168)
                     const float xn[4] = {__fadd_rn(xo.x, y[0]), __fadd_rn(xo.y, y[1]), __fadd_rn(xo.z, y[2]), __fadd_rn(xo.w, y[3])};
                     if constexpr (COH)
@@ -502,7 +489,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
                     const float z[4] = {xn[0] * g.x, xn[1] * g.y, xn[2] * g.z, xn[3] * g.w};
                     if constexpr (COH) store_a16_4_sc1(rs_o, ep.Kb_out, t, n, z, l);
                     else store_a16_4(ep.a16_out, ep.Kb_out, t, n, z);
-                    ssq[h][q] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
+                    ssq[s] += xn[0] * xn[0] + xn[1] * xn[1] + xn[2] * xn[2] + xn[3] * xn[3];
                 }
             } else {  // ROPE_KV
                 if (live) {
@@ -569,15 +556,14 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
         // one barrier for all rounds
         float (*ss_lds)[2][TB * 16] = reinterpret_cast<float (*)[2][TB * 16]>(lds_dyn);
 #pragma unroll
-        for (int h = 0; h < ROUNDS; h++)
-#pragma unroll
-            for (int q = 0; q < IPT; q++) {
-                float sq = ssq[h][q];
-                sq += __shfl_xor(sq, 16, 64);
-                sq += __shfl_xor(sq, 32, 64);
-                const int e = tid + q * NW * 64;
-                if (e < ITEMS && (e & 63) < 16) ss_lds[h][(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
-            }
+        for (int s = 0; s < FPT; s++) {
+            float sq = ssq[s];
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const int w_ = tid + s * NW * 64;
+            const int h = w_ >> ITEMS_SHIFT, e = w_ & (ITEMS - 1);
+            if (w_ < WITEMS && (e & 63) < 16) ss_lds[h][(e >> 6) / TB][((e >> 6) % TB) * 16 + (e & 15)] = sq;
+        }
         __syncthreads();
 #pragma unroll
         for (int h = 0; h < ROUNDS; h++) {
@@ -598,7 +584,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& p, const TileIdx ix, u
 #ifdef NVLLM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores issued so far have left the CU
 #endif
-    NVLLM_TSTAMP(6, ssq[0][0]);
+    NVLLM_TSTAMP(6, ssq[0]);
     return true;
 }
 
